@@ -1,0 +1,664 @@
+// Colored element assembly for gfx950: one launch per color batch does the whole
+// chain of src/assemble.cu:1559-1738 (Jacobian -> inverse/det -> shape gradients
+// -> metric -> nodal gathers -> quadrature interpolation -> element tensor ->
+// race-free scatter) without the reference's 22-24 launches and ~1 KB/elem of
+// intermediate global traffic per batch.
+//
+// HBM view (what bounds these kernels):
+//   LHS : per tet 16 (a,b) blocks x one 128-byte line RMW in the block-CSR value
+//         array (4096 B/tet algorithmic) + 80 B of batch-ordered ien/nzmap stream
+//         + L2/MALL-resident node gathers.  The element blocks are transposed
+//         through LDS so that every wave instruction of the scatter touches 8
+//         whole lines (8 lanes x 16 B per line) instead of 64 partial ones.
+//   RHS : per tet 4 nodes x 14 gathered f64 and 24 f64 RMW into F.
+// Summation order inside a matrix entry / F entry is color order, as in the
+// reference (non-atomic colored scatter, assemble.cu:188-208, matrix_impl.cu:447).
+#include "dfl_common.hpp"
+#include <cmath>
+
+namespace {
+
+// ---- constants: src/assemble.cu:23-52,65-118 -------------------------------------
+#define kRHOC (0.5)
+#define kDT (5e-2)
+#define kALPHAM ((3.0 - kRHOC) / (1.0 + kRHOC))
+#define kALPHAF (1.0 / (1.0 + kRHOC))
+#define kGAMMA (0.5 + kALPHAM - kALPHAF)
+#define kRHO (1.0e3)
+#define kCP (1.0)
+#define kKAPPA (0.66)
+#define kMU (10.0 / 3.0)
+#define GW (0.0416666666666667)
+#define GWB (0.1666666666666667)
+#define SHA (0.5854101966249685)
+#define SHB (0.1381966011250105)
+#define FB0 (0.0)
+#define FB1 (0.0)
+#define FB2 (-9.81 * 0.0)
+
+__device__ __forceinline__ double shl(int a, int q) { return a == q ? SHA : SHB; }
+
+__constant__ double c_shlub[48] = {
+    0.0, GWB, GWB, 0.6666666666666667, 0.0, GWB, 0.6666666666666667, GWB, 0.0, 0.6666666666666667, GWB, GWB,
+    GWB, 0.0, GWB, 0.6666666666666667, GWB, 0.0, 0.6666666666666667, GWB, 0.6666666666666667, 0.0, GWB, GWB,
+    0.6666666666666667, GWB, 0.0, GWB, GWB, 0.6666666666666667, 0.0, GWB, GWB, GWB, 0.0, 0.6666666666666667,
+    GWB, 0.6666666666666667, GWB, 0.0, GWB, GWB, 0.6666666666666667, 0.0, 0.6666666666666667, GWB, GWB, 0.0};
+__constant__ double c_nv2[12] = {1.0, 1.0, 1.0, -1.0, 0.0, 0.0, 0.0, -1.0, 0.0, 0.0, 0.0, -1.0};
+
+// Geometry of one tet from its 4 vertices (x[a*3+d]):
+//   invJ column-major (invJ[i+3j] = dxi_i/dx_j), detJ = |det J|, shg[a*3+d],
+//   G = metric of assemble.cu:1586-1593 (G(i,j) = sum_r dxi_i/dx_r dxi_j/dx_r).
+// Closed-form 3x3 inverse replaces the batched pivoted LU (differs by rounding only, Q8).
+__device__ __forceinline__ void tet_geometry(const double* x, double* invJ, double& detJ, double* shg) {
+    const double j00 = x[3] - x[0], j10 = x[4] - x[1], j20 = x[5] - x[2];   // column 0 = x1 - x0
+    const double j01 = x[6] - x[0], j11 = x[7] - x[1], j21 = x[8] - x[2];   // column 1 = x2 - x0
+    const double j02 = x[9] - x[0], j12 = x[10] - x[1], j22 = x[11] - x[2]; // column 2 = x3 - x0
+    const double c00 = j11 * j22 - j12 * j21;
+    const double c01 = j12 * j20 - j10 * j22;
+    const double c02 = j10 * j21 - j11 * j20;
+    const double det = j00 * c00 + j01 * c01 + j02 * c02;
+    const double id = 1.0 / det;
+    detJ = fabs(det);
+    // inverse(i,j) = cof(j,i)/det
+    invJ[0 + 3 * 0] = c00 * id;
+    invJ[0 + 3 * 1] = (j02 * j21 - j01 * j22) * id;
+    invJ[0 + 3 * 2] = (j01 * j12 - j02 * j11) * id;
+    invJ[1 + 3 * 0] = c01 * id;
+    invJ[1 + 3 * 1] = (j00 * j22 - j02 * j20) * id;
+    invJ[1 + 3 * 2] = (j02 * j10 - j00 * j12) * id;
+    invJ[2 + 3 * 0] = c02 * id;
+    invJ[2 + 3 * 1] = (j01 * j20 - j00 * j21) * id;
+    invJ[2 + 3 * 2] = (j00 * j11 - j01 * j10) * id;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) shg[i * 3 + j + 3] = invJ[i + j * 3];  // GetShapeGradKernel, :1308-1328
+    shg[0] = -shg[3] - shg[6] - shg[9];
+    shg[1] = -shg[4] - shg[7] - shg[10];
+    shg[2] = -shg[5] - shg[8] - shg[11];
+}
+
+__device__ __forceinline__ void tet_metric(const double* shg, double* G) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) s += shg[3 + r + 3 * i] * shg[3 + r + 3 * j];
+            G[i + 3 * j] = s;
+        }
+}
+
+// ====================================================================================
+//  LHS: AssembleWeakFormLHSKernel (assemble.cu:495-759) + SetBlockValueToSubmatKernel
+//  (matrix_impl.cu:370-453), 16 lanes per element, 16 elements per 256-thread block.
+// ====================================================================================
+constexpr int EPB = 16;
+constexpr int LBLK = 256;
+constexpr int TRS = 257;  // padded row length of the transpose buffer
+
+__global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict__ ien_b, const I* __restrict__ nzmap_b,
+                                                      const T* __restrict__ xg, const T* __restrict__ wg, T* __restrict__ val) {
+    __shared__ double s_x[EPB][12];
+    __shared__ double s_u[EPB][12];
+    __shared__ double s_shg[EPB][12];
+    __shared__ double s_conv[EPB][4][4];  // [a][q]
+    __shared__ double s_tau[EPB][4][2];   // [q][tauM, tauC]
+    __shared__ double s_scal[EPB][4];     // detJ, gg, 1/tr
+    __shared__ double s_blk[16 * TRS];
+    __shared__ int s_nz[LBLK];
+
+    const int t = threadIdx.x;
+    const int te = t >> 4, p = t & 15;
+    const long long e = (long long)blockIdx.x * EPB + te;
+    const bool valid = e < B;
+
+    s_nz[t] = valid ? nzmap_b[(long long)blockIdx.x * LBLK + t] : -1;
+    if (valid && p < 12) {
+        const int a = p / 3, d = p - a * 3;
+        const long long node = ien_b[e * 4 + a];
+        s_x[te][p] = xg[3 * node + d];
+        s_u[te][p] = wg[3 * node + d];
+    }
+    __syncthreads();
+
+    if (valid && p == 0) {
+        double invJ[9], shg[12], G[9], detJ;
+        tet_geometry(s_x[te], invJ, detJ, shg);
+        tet_metric(shg, G);
+        double gg = 0.0, tr = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {  // :528-533
+            gg += G[i] * G[i];
+            if (!(i & 3)) tr += G[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s_shg[te][i] = shg[i];
+        s_scal[te][0] = detJ;
+        s_scal[te][1] = gg;
+        s_scal[te][2] = 1.0 / tr;
+    }
+    __syncthreads();
+
+    if (valid) {  // p = a*4 + q : shconv[a] at quadrature point q (:574-583)
+        const int a = p >> 2, q = p & 3;
+        double uq[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double s = 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s += shl(b, q) * s_u[te][b * 3 + d];  // qr_wgalpha, :1648-1655
+            uq[d] = s;
+        }
+        double c = 0.0;
+        c += s_shg[te][a * 3 + 0] * uq[0];
+        c += s_shg[te][a * 3 + 1] * uq[1];
+        c += s_shg[te][a * 3 + 2] * uq[2];
+        s_conv[te][a][q] = c;
+    }
+    __syncthreads();
+
+    if (valid && p < 4) {  // stabilisation parameters at quadrature point p (:587-603)
+        const double knu = kMU / kRHO;
+        double tmp = 0.0;
+        tmp += s_conv[te][1][p] * s_conv[te][1][p];
+        tmp += s_conv[te][2][p] * s_conv[te][2][p];
+        tmp += s_conv[te][3][p] * s_conv[te][3][p];
+        const double gg = s_scal[te][1];
+        s_tau[te][p][0] = (1.0 / sqrt(4.0 / (kDT * kDT) + tmp + 3.0 * knu * knu * gg)) / kRHO;
+        s_tau[te][p][1] = sqrt(tmp + 3.0 * knu * knu * gg) * s_scal[te][2];
+    }
+    __syncthreads();
+
+    double Bk[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Bk[i] = 0.0;
+    if (valid) {
+        const int aa = p >> 2, bb = p & 3;
+        const double fact1 = kALPHAM;
+        const double fact2 = kDT * kALPHAF * kGAMMA;
+        const double detJ = s_scal[te][0];
+        double ga[3], gb[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            ga[d] = s_shg[te][aa * 3 + d];
+            gb[d] = s_shg[te][bb * 3 + d];
+        }
+        const double eK = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+#pragma unroll
+        for (int iq = 0; iq < 4; ++iq) {
+            const double tau0 = s_tau[te][iq][0], tau1 = s_tau[te][iq][1];
+            const double ca = s_conv[te][aa][iq], cb = s_conv[te][bb][iq];
+            const double sa = shl(aa, iq), sb = shl(bb, iq);
+            const double detJgw = detJ * GW;
+            double tmp = 0.0;
+            tmp += fact1 * kRHO * sa * sb;
+            tmp += fact1 * kRHO * kRHO * tau0 * ca * sb;
+            tmp += fact2 * sa * kRHO * cb;
+            tmp += fact2 * tau0 * kRHO * ca * kRHO * cb;
+            tmp += fact2 * kMU * eK;
+            Bk[0] += tmp * detJgw;
+            Bk[5] += tmp * detJgw;
+            Bk[10] += tmp * detJgw;
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    Bk[ii * 4 + jj] += fact2 * kMU * ga[jj] * gb[ii] * detJgw;
+                    Bk[ii * 4 + jj] += fact2 * kRHO * tau1 * ga[ii] * gb[jj] * detJgw;
+                }
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii) {  // dRM/dP
+                Bk[ii * 4 + 3] -= ga[ii] * sb * detJgw;
+                Bk[ii * 4 + 3] += kRHO * tau0 * ca * gb[ii] * detJgw;
+            }
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii) {  // dRC/dU
+                Bk[12 + ii] += fact1 * kRHO * tau0 * ga[ii] * sb * detJgw;
+                Bk[12 + ii] += fact2 * sa * gb[ii] * detJgw;
+                Bk[12 + ii] += fact2 * tau0 * ga[ii] * kRHO * cb * detJgw;
+            }
+            Bk[15] += tau0 * eK * detJgw;  // dRC/dP
+        }
+    }
+    // transpose through LDS: s_blk[i][t] = entry i of the block owned by thread t
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_blk[i * TRS + t] = Bk[i];
+    __syncthreads();
+
+    // scatter: 8 lanes per 128-byte block line, 32 blocks per pass, 8 passes
+    const int l8 = t & 7;
+    double2 oldv[8];
+    long long addr[8];
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int bi = (t >> 3) + 32 * pass;
+        const int nz = s_nz[bi];
+        addr[pass] = (nz >= 0) ? ((long long)nz * 16 + 2 * l8) : -1;
+        if (nz >= 0) oldv[pass] = *reinterpret_cast<const double2*>(val + addr[pass]);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int bi = (t >> 3) + 32 * pass;
+        if (addr[pass] >= 0) {
+            double2 nv;
+            nv.x = oldv[pass].x + s_blk[(2 * l8) * TRS + bi];
+            nv.y = oldv[pass].y + s_blk[(2 * l8 + 1) * TRS + bi];
+            *reinterpret_cast<double2*>(val + addr[pass]) = nv;
+        }
+    }
+}
+
+// ====================================================================================
+//  RHS: AssembleWeakFormKernel<..,1> (assemble.cu:761-924) + ElemRHSLocal2Global x4
+//  (:188-208, 1709-1724).  4 lanes per element: lane = node a for the gather and the
+//  scatter, lane = quadrature point q for the weak form; the 4 quadrature
+//  contributions are summed across the lanes by two xor-shuffles.
+// ====================================================================================
+constexpr int RBLK = 256;
+constexpr int REPB = RBLK / 4;
+constexpr int NV = 14;  // x(3) u(3) phi T du(3) p dphi dT per node
+
+__device__ __forceinline__ double quad_sum(double v) {
+    v += __shfl_xor(v, 1, WAVE);
+    v += __shfl_xor(v, 2, WAVE);
+    return v;
+}
+
+__global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict__ ien_b, I N, const T* __restrict__ xg,
+                                                      const T* __restrict__ wg, const T* __restrict__ dwg, T* __restrict__ F) {
+    __shared__ double s_n[REPB][4][NV + 1];
+    const int t = threadIdx.x;
+    const int te = t >> 2, a = t & 3;
+    const long long e = (long long)blockIdx.x * REPB + te;
+    const bool valid = e < B;
+    long long node = 0;
+    if (valid) {
+        node = ien_b[e * 4 + a];
+        double* s = s_n[te][a];
+        s[0] = xg[3 * node]; s[1] = xg[3 * node + 1]; s[2] = xg[3 * node + 2];
+        s[3] = wg[3 * node]; s[4] = wg[3 * node + 1]; s[5] = wg[3 * node + 2];
+        s[6] = wg[4LL * N + node];
+        s[7] = wg[5LL * N + node];
+        s[8] = dwg[3 * node]; s[9] = dwg[3 * node + 1]; s[10] = dwg[3 * node + 2];
+        s[11] = dwg[3LL * N + node];  // pressure always from the rate vector (Q9, :1606-1609)
+        s[12] = dwg[4LL * N + node];
+        s[13] = dwg[5LL * N + node];
+    }
+    __syncthreads();
+    if (!valid) return;  // whole 4-lane groups leave together; shuffles below stay inside a group
+
+    const int iq = a;
+    double x[12];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) x[b * 3 + d] = s_n[te][b][d];
+    double invJ[9], shg[12], G[9], detJ;
+    tet_geometry(x, invJ, detJ, shg);
+    tet_metric(shg, G);
+
+    // buffer[comp][b] of LoadElementValueKernel: wg: u0 u1 u2 p phi T ; dwg: du0 du1 du2 p dphi dT
+    const int wsrc[6] = {3, 4, 5, 11, 6, 7};
+    const int dsrc[6] = {8, 9, 10, 11, 12, 13};
+    double grad[18], qw[6], qd[6];
+#pragma unroll
+    for (int comp = 0; comp < 6; ++comp) {
+        double vb[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) vb[b] = s_n[te][b][wsrc[comp]];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double s = 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s += shg[d + 3 * b] * vb[b];
+            grad[d + 3 * comp] = s;  // qr_wggradalpha, :1628-1635
+        }
+        double s = 0.0, sd = 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            s += shl(b, iq) * vb[b];
+            sd += shl(b, iq) * s_n[te][b][dsrc[comp]];
+        }
+        qw[comp] = s;   // qr_wgalpha[comp][iq]
+        qd[comp] = sd;  // qr_dwgalpha[comp][iq]
+    }
+
+    const double fb[3] = {FB0, FB1, FB2};
+    const double divu = grad[0] + grad[4] + grad[8];
+    double uadv[3] = {qw[0], qw[1], qw[2]};
+    double rLi[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double r = 0.0;
+        r += kRHO * (qd[i] - fb[i]);
+        r += kRHO * uadv[0] * grad[3 * i + 0];
+        r += kRHO * uadv[1] * grad[3 * i + 1];
+        r += kRHO * uadv[2] * grad[3 * i + 2];
+        r += grad[3 * 3 + i];
+        rLi[i] = r;
+    }
+    // GetStabTau, :444-484
+    double tau[4];
+    {
+        double t0 = 4.0 / (kDT * kDT), t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                t1 += G[i * 3 + j] * uadv[i] * uadv[j];
+                t2 += G[i * 3 + j] * G[i * 3 + j];
+            }
+        const double mu = kMU / kRHO, kappa = kKAPPA / (kRHO * kCP);
+        tau[0] = (1.0 / sqrt(t0 + t1 + 3.0 * mu * mu * t2)) / kRHO;
+        tau[1] = sqrt(t1 + 3.0 * mu * mu * t2) / (G[0] + G[4] + G[8]);
+        tau[2] = 1.0 / sqrt(t0 + t1);
+        tau[3] = (1.0 / sqrt(t0 + t1 + 3.0 * kappa * kappa * t2)) / (kRHO * kCP);
+    }
+    double shconv[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        double c = 0.0;
+        c += uadv[0] * shg[b * 3 + 0];
+        c += uadv[1] * shg[b * 3 + 1];
+        c += uadv[2] * shg[b * 3 + 2];
+        shconv[b] = c;
+    }
+    double tmp0[3], tmp1[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double v = 0.0;
+        v += kRHO * (qd[i] - fb[i]);
+        v += kRHO * (uadv[0] - tau[0] * rLi[0]) * grad[3 * i + 0];
+        v += kRHO * (uadv[1] - tau[0] * rLi[1]) * grad[3 * i + 1];
+        v += kRHO * (uadv[2] - tau[0] * rLi[2]) * grad[3 * i + 2];
+        tmp0[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double v = 0.0;
+            v += kMU * (grad[3 * i + j] + grad[3 * j + i]);
+            v += kRHO * tau[0] * rLi[i] * uadv[j];
+            v -= kRHO * tau[0] * tau[0] * rLi[i] * rLi[j];
+            tmp1[i * 3 + j] = v;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tmp1[i * 3 + i] += -qw[3] + kRHO * tau[1] * divu;
+
+    const double wq = GW * detJ;
+    const double bp = qd[4] + uadv[0] * grad[3 * 4 + 0] + uadv[1] * grad[3 * 4 + 1] + uadv[2] * grad[3 * 4 + 2];
+    const double btc = kRHO * kCP * (qd[5] + uadv[0] * grad[3 * 5 + 0] + uadv[1] * grad[3 * 5 + 1] + uadv[2] * grad[3 * 5 + 2]);
+    double mine[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+        double c[6];
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+            double bm = 0.0;
+            bm += shl(aa, iq) * tmp0[ii];
+            bm += shg[aa * 3 + 0] * tmp1[ii * 3 + 0];
+            bm += shg[aa * 3 + 1] * tmp1[ii * 3 + 1];
+            bm += shg[aa * 3 + 2] * tmp1[ii * 3 + 2];
+            c[ii] = bm * GW * detJ;
+        }
+        {
+            double bc = 0.0;
+            bc += shl(aa, iq) * divu;
+            bc += tau[0] * rLi[0] * shg[aa * 3 + 0];
+            bc += tau[0] * rLi[1] * shg[aa * 3 + 1];
+            bc += tau[0] * rLi[2] * shg[aa * 3 + 2];
+            c[3] = bc * GW * detJ;
+        }
+        c[4] = bp * (shl(aa, iq) + tau[2] * shconv[aa]) * GW * detJ;
+        {
+            double bt = btc * (shl(aa, iq) + kRHO * kCP * tau[3] * shconv[aa]);
+            bt += kKAPPA * (grad[3 * 5 + 0] * shg[aa * 3 + 0] + grad[3 * 5 + 1] * shg[aa * 3 + 1] + grad[3 * 5 + 2] * shg[aa * 3 + 2]);
+            c[5] = bt * GW * detJ;
+        }
+        (void)wq;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const double tot = quad_sum(c[j]);  // sum over the 4 quadrature points
+            if (aa == a) mine[j] = tot;
+        }
+    }
+    // ElemRHSLocal2Global: non-atomic, race-free inside a color
+    F[3 * node + 0] += mine[0];
+    F[3 * node + 1] += mine[1];
+    F[3 * node + 2] += mine[2];
+    F[3LL * N + node] += mine[3];
+    F[4LL * N + node] += mine[4];
+    F[5LL * N + node] += mine[5];
+}
+
+// ====================================================================================
+//  Faces: GetElemFaceNVKernel (:279-319) + FaceAssemblyKernel (:1038-1214), one
+//  thread per face of one parent color.
+// ====================================================================================
+__device__ __forceinline__ int find_nz(const I* __restrict__ rp, const I* __restrict__ ci, int row, int col) {
+    int lo = rp[row], hi = rp[row + 1] - 1;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (ci[mid] < col) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(64) void face_kernel(I nf, const I* __restrict__ face_list, const I* __restrict__ f2e,
+                                                 const I* __restrict__ forn, const I* __restrict__ ien, I N,
+                                                 const T* __restrict__ xg, const T* __restrict__ wg, const T* __restrict__ dwg,
+                                                 T* __restrict__ F, const I* __restrict__ rp, const I* __restrict__ ci,
+                                                 T* __restrict__ val) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nf) return;
+    const int f = face_list ? face_list[i] : i;
+    const long long el = f2e[f];
+    const int iorn = forn[f];
+    int nodes[4];
+    double x[12], buf[4][4];  // buf[comp][a], comps u0 u1 u2 p
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        nodes[a] = ien[el * 4 + a];
+        const long long n = nodes[a];
+        x[a * 3 + 0] = xg[3 * n]; x[a * 3 + 1] = xg[3 * n + 1]; x[a * 3 + 2] = xg[3 * n + 2];
+        buf[0][a] = wg[3 * n]; buf[1][a] = wg[3 * n + 1]; buf[2][a] = wg[3 * n + 2];
+        buf[3][a] = dwg[3LL * N + n];
+    }
+    double invJ[9], shg[12], detJ;
+    tet_geometry(x, invJ, detJ, shg);
+    double nv[3];
+    {
+        double b[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) b[n] += invJ[n * 3 + k] * c_nv2[iorn * 3 + k];
+        nv[0] = b[0] * detJ; nv[1] = b[1] * detJ; nv[2] = b[2] * detJ;
+    }
+    double grad[12];  // comps 0..3 (phi/T rows of the reference buffer are zero)
+#pragma unroll
+    for (int comp = 0; comp < 4; ++comp)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s += shg[d + 3 * a] * buf[comp][a];
+            grad[d + 3 * comp] = s;
+        }
+    const double* sb = c_shlub + 12 * iorn;
+    double qb[4][3];
+#pragma unroll
+    for (int comp = 0; comp < 4; ++comp)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s += sb[a + 4 * q] * buf[comp][a];
+            qb[comp][q] = s;
+        }
+    double hinv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double w = invJ[k + 0] * nv[0] + invJ[k + 3] * nv[1] + invJ[k + 6] * nv[2];
+        hinv += w * w;
+    }
+    hinv = sqrt(hinv);
+    const double tau_b = 4.0 * kMU * hinv;
+
+    if (F) {
+        double eF[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) eF[a][j] = 0.0;
+#pragma unroll
+        for (int iq = 0; iq < 3; ++iq) {
+            const double uadv[3] = {qb[0][iq], qb[1][iq], qb[2][iq]};
+            const double unor = uadv[0] * nv[0] + uadv[1] * nv[1] + uadv[2] * nv[2];
+            const double uneg = (unor - fabs(unor)) * 0.5;
+            double tmp0[3], tmp1[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double v = 0.0;
+                v += nv[k] * qb[3][iq];
+                v -= kMU * (nv[0] * grad[3 * k + 0] + nv[1] * grad[3 * k + 1] + nv[2] * grad[3 * k + 2]);
+                v -= kMU * (nv[0] * grad[3 * 0 + k] + nv[1] * grad[3 * 1 + k] + nv[2] * grad[3 * 2 + k]);
+                v -= kRHO * uneg * uadv[k];
+                v += tau_b * uadv[k];
+                tmp0[k] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) tmp1[k * 3 + j] = -kMU * (nv[k] * uadv[j] + nv[j] * uadv[k]);
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii) {
+                    double bm = 0.0;
+                    bm += sb[iq * 4 + aa] * tmp0[ii];
+                    bm += shg[aa * 3 + 0] * tmp1[ii * 3 + 0];
+                    bm += shg[aa * 3 + 1] * tmp1[ii * 3 + 1];
+                    bm += shg[aa * 3 + 2] * tmp1[ii * 3 + 2];
+                    eF[aa][ii] += bm * GWB;
+                }
+                eF[aa][3] -= sb[iq * 4 + aa] * unor * GWB;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const long long n = nodes[a];
+            F[3 * n + 0] += eF[a][0];
+            F[3 * n + 1] += eF[a][1];
+            F[3 * n + 2] += eF[a][2];
+            F[3LL * N + n] += eF[a][3];
+        }
+    }
+    if (val) {
+        const double fact2 = kDT * kALPHAF * kGAMMA;
+        double shnorm[4];
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            double s = 0.0;
+            s += shg[aa * 3 + 0] * nv[0];
+            s += shg[aa * 3 + 1] * nv[1];
+            s += shg[aa * 3 + 2] * nv[2];
+            shnorm[aa] = s;
+        }
+        for (int aa = 0; aa < 4; ++aa)
+            for (int bb = 0; bb < 4; ++bb) {
+                double Bk[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) Bk[k] = 0.0;
+#pragma unroll
+                for (int iq = 0; iq < 3; ++iq) {
+                    const double uadv[3] = {qb[0][iq], qb[1][iq], qb[2][iq]};
+                    const double unor = uadv[0] * nv[0] + uadv[1] * nv[1] + uadv[2] * nv[2];
+                    const double uneg = (unor - fabs(unor)) * 0.5;
+                    const double sa = sb[iq * 4 + aa], sbb = sb[iq * 4 + bb];
+                    double tmp0 = 0.0;
+                    tmp0 -= kMU * (shnorm[bb] * sa + shnorm[aa] * sbb);
+                    tmp0 -= kRHO * sa * sbb * uneg;
+                    tmp0 += tau_b * sa * sbb;
+                    Bk[0] += fact2 * tmp0 * GWB;
+                    Bk[5] += fact2 * tmp0 * GWB;
+                    Bk[10] += fact2 * tmp0 * GWB;
+#pragma unroll
+                    for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+                        for (int jj = 0; jj < 3; ++jj) {
+                            double v = 0.0;
+                            v -= kMU * sa * shg[bb * 3 + ii] * nv[jj];
+                            v -= kMU * sbb * shg[aa * 3 + jj] * nv[ii];
+                            Bk[ii * 4 + jj] += fact2 * v * GWB;
+                        }
+                    const double ss = sa * sbb;
+#pragma unroll
+                    for (int ii = 0; ii < 3; ++ii) {
+                        Bk[12 + ii] -= fact2 * ss * nv[ii] * GWB;  // dRC/dU
+                        Bk[ii * 4 + 3] += ss * nv[ii] * GWB;       // dRM/dP
+                    }
+                }
+                const int nz = find_nz(rp, ci, nodes[aa], nodes[bb]);
+                T* dst = val + (long long)nz * 16;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) dst[k] += Bk[k];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void nzmap_kernel(I T_, const I* __restrict__ ien_b, const I* __restrict__ rp,
+                                                   const I* __restrict__ ci, I* __restrict__ nzmap) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)T_ * 16) return;
+    const long long e = i >> 4;
+    const int p = (int)(i & 15), aa = p >> 2, bb = p & 3;
+    nzmap[i] = find_nz(rp, ci, ien_b[e * 4 + aa], ien_b[e * 4 + bb]);
+}
+
+__global__ __launch_bounds__(256) void gather_ien_kernel(I T_, const I* __restrict__ ien, const I* __restrict__ batch_ind,
+                                                        I* __restrict__ ien_b) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)T_ * 4) return;
+    ien_b[i] = ien[(long long)batch_ind[i >> 2] * 4 + (i & 3)];
+}
+
+}  // namespace
+
+extern "C" {
+
+void dfl_assemble_tet_lhs(I B, const I* ien_b, const I* nzmap_b, const T* xg, const T* wg, T* val, void* stream) {
+    if (B <= 0) return;
+    tet_lhs_kernel<<<ceil_div(B, EPB), LBLK, 0, S(stream)>>>(B, ien_b, nzmap_b, xg, wg, val);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_assemble_tet_rhs(I B, const I* ien_b, I N, const T* xg, const T* wg, const T* dwg, T* F, void* stream) {
+    if (B <= 0) return;
+    tet_rhs_kernel<<<ceil_div(B, REPB), RBLK, 0, S(stream)>>>(B, ien_b, N, xg, wg, dwg, F);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_assemble_face(I nf, const I* face_list, const I* f2e, const I* forn, const I* ien, I N, const T* xg, const T* wg,
+                       const T* dwg, T* F, const I* rp, const I* ci, T* val, void* stream) {
+    if (nf <= 0) return;
+    face_kernel<<<ceil_div(nf, 64), 64, 0, S(stream)>>>(nf, face_list, f2e, forn, ien, N, xg, wg, dwg, F, rp, ci, val);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_elem_nzmap(I T_, const I* ien_b, const I* rp, const I* ci, I* nzmap_b, void* stream) {
+    if (T_ <= 0) return;
+    nzmap_kernel<<<ceil_div((long long)T_ * 16, 256), 256, 0, S(stream)>>>(T_, ien_b, rp, ci, nzmap_b);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_gather_ien(I T_, const I* ien, const I* batch_ind, I* ien_b, void* stream) {
+    if (T_ <= 0) return;
+    gather_ien_kernel<<<ceil_div((long long)T_ * 4, 256), 256, 0, S(stream)>>>(T_, ien, batch_ind, ien_b);
+    DFL_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,360 @@
+// BLAS-1, deterministic reductions, fused classical Gram-Schmidt and the GMRES
+// small recurrences -- replaces the cuBLAS calls of src/krylov.c:114-319,
+// src/main.c:107-130 and the elementwise kernels of src/vec.cu:14-76.
+// All of these are HBM-bound streams: 16-byte accesses per lane, grid sized to
+// a few blocks per CU, two-stage (order-fixed) reductions instead of atomics so
+// that Krylov residual histories are bitwise reproducible run to run.
+#include "dfl_common.hpp"
+#include <cmath>
+
+static char g_err[512] = "";
+void dfl_record_error(hipError_t e, const char* file, int line) {
+    snprintf(g_err, sizeof g_err, "HIP error: %s at %s:%d", hipGetErrorString(e), file, line);
+    fprintf(stderr, "GPUAssert: %s\n", g_err);
+}
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr int MAX_PART = 1024;  // stage-1 partials of a reduction
+
+template <class F>
+__global__ __launch_bounds__(BLK) void map1(I n, T* x, F f) {
+    long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    long long n2 = n >> 1;
+    if (i < n2) {
+        double2 v = reinterpret_cast<double2*>(x)[i];
+        v.x = f(v.x);
+        v.y = f(v.y);
+        reinterpret_cast<double2*>(x)[i] = v;
+    }
+    if (i == 0 && (n & 1)) x[n - 1] = f(x[n - 1]);
+}
+
+template <class F>
+__global__ __launch_bounds__(BLK) void map3(I n, const T* a, const T* b, T* c, F f) {
+    long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    long long n2 = n >> 1;
+    if (i < n2) {
+        double2 u = reinterpret_cast<const double2*>(a)[i];
+        double2 v = reinterpret_cast<const double2*>(b)[i];
+        double2 r;
+        r.x = f(u.x, v.x);
+        r.y = f(u.y, v.y);
+        reinterpret_cast<double2*>(c)[i] = r;
+    }
+    if (i == 0 && (n & 1)) c[n - 1] = f(a[n - 1], b[n - 1]);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <class F>
+__global__ __launch_bounds__(BLK) void map1_scalar(I n, T* x, F f) {
+    long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i < n) x[i] = f(x[i]);
+}
+template <class F>
+__global__ __launch_bounds__(BLK) void map3_scalar(I n, const T* a, const T* b, T* c, F f) {
+    long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i < n) c[i] = f(a[i], b[i]);
+}
+
+template <class F>
+void launch_map1(I n, T* x, F f, void* stream) {
+    if (n <= 0) return;
+    if (aligned16(x)) map1<<<ceil_div((n >> 1) + 1, BLK), BLK, 0, S(stream)>>>(n, x, f);
+    else map1_scalar<<<ceil_div(n, BLK), BLK, 0, S(stream)>>>(n, x, f);
+    DFL_LAUNCH_CHECK();
+}
+template <class F>
+void launch_map3(I n, const T* a, const T* b, T* c, F f, void* stream) {
+    if (n <= 0) return;
+    if (aligned16(a) && aligned16(b) && aligned16(c)) map3<<<ceil_div((n >> 1) + 1, BLK), BLK, 0, S(stream)>>>(n, a, b, c, f);
+    else map3_scalar<<<ceil_div(n, BLK), BLK, 0, S(stream)>>>(n, a, b, c, f);
+    DFL_LAUNCH_CHECK();
+}
+
+// ---- reductions ----------------------------------------------------------------
+template <bool DOT>
+__global__ __launch_bounds__(BLK) void reduce_stage1(I n, const T* x, const T* y, T* part) {
+    __shared__ double lds[4];
+    double acc = 0.0;
+    const long long stride = (long long)gridDim.x * BLK;
+    for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += stride) {
+        double a = x[i];
+        acc += DOT ? a * y[i] : a * a;
+    }
+    double r = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+template <bool SQRT>
+__global__ __launch_bounds__(BLK) void reduce_stage2(int npart, const T* part, T* out) {
+    __shared__ double lds[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < npart; i += BLK) acc += part[i];
+    double r = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) out[0] = SQRT ? sqrt(r) : r;
+}
+
+__global__ __launch_bounds__(BLK) void scal_inv_dev(I n, const T* d_scale, T* x) {
+    const double s = 1.0 / d_scale[0];
+    long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    long long n2 = n >> 1;
+    if (i < n2) {
+        double2 v = reinterpret_cast<double2*>(x)[i];
+        v.x *= s;
+        v.y *= s;
+        reinterpret_cast<double2*>(x)[i] = v;
+    }
+    if (i == 0 && (n & 1)) x[n - 1] *= s;
+}
+
+// ---- fused CGS -------------------------------------------------------------------
+// d_h[j] = Q[:,j].w : grid (row blocks, column tiles of CT); each thread owns
+// RPT double2 row slots, keeps w in registers across the CT columns of its tile.
+constexpr int CT = 8;
+constexpr int RPT = 4;                      // double2 slots per thread
+constexpr int ROWS_PER_BLOCK = BLK * RPT * 2;  // 2048 rows
+
+__global__ __launch_bounds__(BLK) void cgs_dots_stage1(I n, I ncol, const T* __restrict__ Q, long long ldq,
+                                                      const T* __restrict__ w, T* __restrict__ part, int nrb) {
+    __shared__ double lds[4];
+    const long long r0 = (long long)blockIdx.x * ROWS_PER_BLOCK;
+    const int c0 = blockIdx.y * CT;
+    double2 wv[RPT];
+    long long row[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        row[i] = r0 + 2LL * threadIdx.x + (long long)i * (2 * BLK);
+        if (row[i] + 1 < n) wv[i] = *reinterpret_cast<const double2*>(w + row[i]);
+        else { wv[i].x = (row[i] < n) ? w[row[i]] : 0.0; wv[i].y = 0.0; }
+    }
+    for (int c = 0; c < CT; ++c) {
+        const int col = c0 + c;
+        if (col >= ncol) break;  // uniform
+        const T* q = Q + (long long)col * ldq;
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            double2 qv;
+            if (row[i] + 1 < n) qv = *reinterpret_cast<const double2*>(q + row[i]);
+            else { qv.x = (row[i] < n) ? q[row[i]] : 0.0; qv.y = 0.0; }
+            acc += qv.x * wv[i].x + qv.y * wv[i].y;
+        }
+        double r = block_sum_256(acc, lds);
+        if (threadIdx.x == 0) part[(long long)col * nrb + blockIdx.x] = r;
+    }
+}
+
+__global__ __launch_bounds__(BLK) void cgs_dots_stage2(int nrb, const T* part, T* d_h) {
+    __shared__ double lds[4];
+    const T* p = part + (long long)blockIdx.x * nrb;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nrb; i += BLK) acc += p[i];
+    double r = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) d_h[blockIdx.x] = r;
+}
+
+// w -= Q h (SUB) or y = Q c (!SUB); optional partial ||w||^2 per block
+constexpr int UPT = 2;  // double2 slots per thread
+constexpr int UROWS = BLK * UPT * 2;
+template <bool SUB>
+__global__ __launch_bounds__(BLK) void cgs_update_kernel(I n, I ncol, const T* __restrict__ Q, long long ldq,
+                                                        const T* __restrict__ d_h, T* __restrict__ w, T* __restrict__ part) {
+    __shared__ double lds[4];
+    __shared__ double sh[128];
+    for (int j = threadIdx.x; j < ncol && j < 128; j += BLK) sh[j] = d_h[j];
+    __syncthreads();
+    const long long r0 = (long long)blockIdx.x * UROWS;
+    long long row[UPT];
+    double2 acc[UPT];
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+        row[i] = r0 + 2LL * threadIdx.x + (long long)i * (2 * BLK);
+        if (SUB) {
+            if (row[i] + 1 < n) acc[i] = *reinterpret_cast<const double2*>(w + row[i]);
+            else { acc[i].x = (row[i] < n) ? w[row[i]] : 0.0; acc[i].y = 0.0; }
+        } else { acc[i].x = 0.0; acc[i].y = 0.0; }
+    }
+#pragma unroll 4
+    for (int j = 0; j < ncol; ++j) {
+        const double h = (j < 128) ? sh[j] : d_h[j];
+        const T* q = Q + (long long)j * ldq;
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) {
+            double2 qv;
+            if (row[i] + 1 < n) qv = *reinterpret_cast<const double2*>(q + row[i]);
+            else { qv.x = (row[i] < n) ? q[row[i]] : 0.0; qv.y = 0.0; }
+            if (SUB) { acc[i].x -= qv.x * h; acc[i].y -= qv.y * h; }
+            else { acc[i].x += qv.x * h; acc[i].y += qv.y * h; }
+        }
+    }
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+        if (row[i] + 1 < n) *reinterpret_cast<double2*>(w + row[i]) = acc[i];
+        else if (row[i] < n) w[row[i]] = acc[i].x;
+        ss += acc[i].x * acc[i].x + acc[i].y * acc[i].y;
+    }
+    if (part) {
+        double r = block_sum_256(ss, lds);
+        if (threadIdx.x == 0) part[blockIdx.x] = r;
+    }
+}
+
+// ---- GMRES recurrences (single lane; O(k) flops) ----------------------------------
+__device__ void drotg_dev(double* a, double* b, double* c, double* s) {
+    double roe = *b;
+    if (fabs(*a) > fabs(*b)) roe = *a;
+    double scale = fabs(*a) + fabs(*b), r, z;
+    if (scale == 0.0) { *c = 1.0; *s = 0.0; r = 0.0; z = 0.0; }
+    else {
+        double ta = *a / scale, tb = *b / scale;
+        r = scale * sqrt(ta * ta + tb * tb);
+        r = (roe < 0.0 ? -1.0 : 1.0) * r;
+        *c = *a / r; *s = *b / r; z = 1.0;
+        if (fabs(*a) > fabs(*b)) z = *s;
+        if (fabs(*b) >= fabs(*a) && *c != 0.0) z = 1.0 / *c;
+    }
+    *a = r; *b = z;
+}
+
+__global__ void gmres_givens_kernel(I iter, const T* d_nrm, T* H, I ldh, T* gv, T* beta, T* res_hist) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    T* col = H + (long long)iter * ldh;
+    col[iter + 1] = d_nrm[0];  // H[iter+1, iter] = ||w||, krylov.c:228-230
+    for (I i = 0; i < iter; ++i) {  // cublasDrot(n=1), krylov.c:258-263
+        double c = gv[2 * i], s = gv[2 * i + 1];
+        double x = col[i], y = col[i + 1];
+        col[i] = c * x + s * y;
+        col[i + 1] = c * y - s * x;
+    }
+    drotg_dev(&col[iter], &col[iter + 1], &gv[2 * iter], &gv[2 * iter + 1]);  // :266
+    col[iter + 1] = 0.0;                                                     // :267
+    double b0 = beta[iter];                                                  // krylov_util.cu:5-19
+    beta[iter + 1] = -gv[2 * iter + 1] * b0;
+    beta[iter] = b0 * gv[2 * iter];
+    if (res_hist) res_hist[iter] = fabs(beta[iter + 1]);
+}
+
+__global__ void gmres_trsv_kernel(I m, const T* H, I ldh, T* beta) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (I i = m - 1; i >= 0; --i) {
+        double s = beta[i];
+        for (I j = i + 1; j < m; ++j) s -= H[(long long)j * ldh + i] * beta[j];
+        beta[i] = s / H[(long long)i * ldh + i];
+    }
+}
+
+__global__ void sqrt_kernel(T* v) { v[0] = sqrt(v[0]); }
+
+__global__ void residual_update_kernel(T* beta, T* gv) {
+    double b0 = beta[0];
+    beta[1] = -gv[1] * b0;
+    beta[0] = b0 * gv[0];
+}
+
+}  // namespace
+
+extern "C" {
+
+int dfl_abi_version(void) { return 1; }
+const char* dfl_last_error(void) { return g_err; }
+
+void dfl_daxpy(I n, T alpha, const T* x, T* y, void* stream) {
+    launch_map3(n, x, y, y, [alpha] __device__(double a, double b) { return alpha * a + b; }, stream);
+}
+void dfl_dscal(I n, T alpha, T* x, void* stream) {
+    launch_map1(n, x, [alpha] __device__(double a) { return alpha * a; }, stream);
+}
+void dfl_dcopy(I n, const T* x, T* y, void* stream) {
+    if (n > 0) DFL_GUARD(hipMemcpyAsync(y, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, S(stream)));
+}
+void dfl_dset(I n, T alpha, T* x, void* stream) {
+    launch_map1(n, x, [alpha] __device__(double) { return alpha; }, stream);
+}
+void SetValGPU(T* val, I n, T alpha) { dfl_dset(n, alpha, val, nullptr); }
+void dfl_pointwise_mult(I n, const T* x, const T* y, T* z, void* stream) {
+    launch_map3(n, x, y, z, [] __device__(double a, double b) { return a * b; }, stream);
+}
+void dfl_pointwise_div(I n, const T* x, const T* y, T* z, void* stream) {
+    launch_map3(n, x, y, z, [] __device__(double a, double b) { return a / b; }, stream);
+}
+void dfl_pointwise_inv(I n, T* x, void* stream) {
+    launch_map1(n, x, [] __device__(double a) { return 1.0 / a; }, stream);
+}
+
+I dfl_reduce_work_size(void) { return MAX_PART; }
+
+static int reduce_grid(I n) {
+    int g = ceil_div(n, BLK * 8);
+    if (g < 1) g = 1;
+    if (g > MAX_PART) g = MAX_PART;
+    return g;
+}
+void dfl_ddot(I n, const T* x, const T* y, T* d_out, T* work, void* stream) {
+    int g = reduce_grid(n);
+    reduce_stage1<true><<<g, BLK, 0, S(stream)>>>(n, x, y, work);
+    reduce_stage2<false><<<1, BLK, 0, S(stream)>>>(g, work, d_out);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_dnrm2(I n, const T* x, T* d_out, T* work, void* stream) {
+    int g = reduce_grid(n);
+    reduce_stage1<false><<<g, BLK, 0, S(stream)>>>(n, x, x, work);
+    reduce_stage2<true><<<1, BLK, 0, S(stream)>>>(g, work, d_out);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_dscal_inv_dev(I n, const T* d_scale, T* x, void* stream) {
+    if (n <= 0) return;
+    scal_inv_dev<<<ceil_div((n >> 1) + 1, BLK), BLK, 0, S(stream)>>>(n, d_scale, x);
+    DFL_LAUNCH_CHECK();
+}
+
+int64_t dfl_cgs_work_size(I n, I ncol) {
+    int64_t nrb = ceil_div(n, ROWS_PER_BLOCK);
+    int64_t a = nrb * (int64_t)(ncol > 0 ? ncol : 1);
+    int64_t b = ceil_div(n, UROWS);
+    return (a > b ? a : b) + 16;
+}
+void dfl_cgs_dots(I n, I ncol, const T* Q, int64_t ldq, const T* w, T* d_h, T* work, void* stream) {
+    if (ncol <= 0) return;
+    int nrb = ceil_div(n, ROWS_PER_BLOCK);
+    dim3 grid(nrb, ceil_div(ncol, CT));
+    cgs_dots_stage1<<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb);
+    cgs_dots_stage2<<<ncol, BLK, 0, S(stream)>>>(nrb, work, d_h);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_cgs_update(I n, I ncol, const T* Q, int64_t ldq, const T* d_h, T* w, T* d_nrm, int take_sqrt, T* work, void* stream) {
+    int g = ceil_div(n, UROWS);
+    cgs_update_kernel<true><<<g, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, d_h, w, d_nrm ? work : nullptr);
+    if (d_nrm) {
+        if (take_sqrt) reduce_stage2<true><<<1, BLK, 0, S(stream)>>>(g, work, d_nrm);
+        else reduce_stage2<false><<<1, BLK, 0, S(stream)>>>(g, work, d_nrm);
+    }
+    DFL_LAUNCH_CHECK();
+}
+void dfl_dsqrt_dev(T* d_val, void* stream) {
+    sqrt_kernel<<<1, 1, 0, S(stream)>>>(d_val);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_gemv_n(I n, I ncol, const T* Q, int64_t ldq, const T* d_c, T* y, void* stream) {
+    int g = ceil_div(n, UROWS);
+    cgs_update_kernel<false><<<g, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, d_c, y, nullptr);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_gmres_givens(I iter, const T* d_nrm, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, void* stream) {
+    gmres_givens_kernel<<<1, 64, 0, S(stream)>>>(iter, d_nrm, d_H, ldh, d_gv, d_beta, d_res_hist);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_gmres_trsv(I m, const T* d_H, I ldh, T* d_beta, void* stream) {
+    gmres_trsv_kernel<<<1, 64, 0, S(stream)>>>(m, d_H, ldh, d_beta);
+    DFL_LAUNCH_CHECK();
+}
+void GMRESResidualUpdatePrivate(T* beta, T* gv) {
+    residual_update_kernel<<<1, 1>>>(beta, gv);
+    DFL_LAUNCH_CHECK();
+}
+
+}  // extern "C"

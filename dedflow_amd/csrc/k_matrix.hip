@@ -1,0 +1,364 @@
+// Block-CSR SpMV, block-Jacobi preconditioner, diagonal extraction, Dirichlet
+// row elimination and layout conversion.
+//
+// Layout (see include/dedflow_kernels.h): val[k*16 + r*4 + c], one 128-byte
+// line per nodal nonzero, so a node row is one contiguous run of len*128 B.
+// SpMV maps 8 lanes to a node row: lane l owns block entries (2l, 2l+1), i.e.
+// one 16-byte load per lane and one full 128-byte line per 8 lanes -- every
+// wave instruction touches 8 whole lines, which is what the HBM roofline needs
+// (algorithmic bytes 132*nnz1 + 4(N+1) + 64N).
+#include "dfl_common.hpp"
+
+namespace {
+
+constexpr int BLK = 256;
+
+// x index of block column c (0..3) of node `col` in the [u AoS | p] layout
+__device__ __forceinline__ long long xidx(int col, int c, long long N3) { return c < 3 ? 3LL * col + c : N3 + col; }
+
+template <bool BETA0>
+__global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I N, const I* __restrict__ rp, const I* __restrict__ ci,
+                                                       const T* __restrict__ val, T alpha, const T* __restrict__ x, T beta,
+                                                       T* __restrict__ y) {
+    const long long gid = (long long)blockIdx.x * BLK + threadIdx.x;
+    const int row = (int)(gid >> 3);
+    const int l = threadIdx.x & 7;
+    if (row >= N) return;  // whole 8-lane group leaves together
+    const long long N3 = 3LL * N;
+    const int r = l >> 1;
+    const bool hi = (l & 1);  // false: columns (u0,u1); true: columns (u2,p)
+    const int s = rp[row], e = rp[row + 1];
+    const double2* __restrict__ v2 = reinterpret_cast<const double2*>(val) + l;
+    double acc0 = 0.0, acc1 = 0.0;
+    int k = s;
+    for (; k + 1 < e; k += 2) {
+        const int c0 = ci[k], c1 = ci[k + 1];
+        const double2 a0 = v2[(long long)k * 8];
+        const double2 a1 = v2[(long long)(k + 1) * 8];
+        const double x00 = hi ? x[3LL * c0 + 2] : x[3LL * c0];
+        const double x01 = hi ? x[N3 + c0] : x[3LL * c0 + 1];
+        const double x10 = hi ? x[3LL * c1 + 2] : x[3LL * c1];
+        const double x11 = hi ? x[N3 + c1] : x[3LL * c1 + 1];
+        acc0 += a0.x * x00 + a0.y * x01;
+        acc1 += a1.x * x10 + a1.y * x11;
+    }
+    if (k < e) {
+        const int c0 = ci[k];
+        const double2 a0 = v2[(long long)k * 8];
+        const double x00 = hi ? x[3LL * c0 + 2] : x[3LL * c0];
+        const double x01 = hi ? x[N3 + c0] : x[3LL * c0 + 1];
+        acc0 += a0.x * x00 + a0.y * x01;
+    }
+    double acc = acc0 + acc1;
+    acc += __shfl_xor(acc, 1, WAVE);
+    if (!hi) {
+        const long long yi = xidx(row, r, N3);
+        y[yi] = BETA0 ? alpha * acc : alpha * acc + beta * y[yi];
+    }
+}
+
+// scalar CSR, 8 lanes per row (reference-layout sub-matrices)
+__global__ __launch_bounds__(BLK) void csr_spmv_kernel(I nrow, const I* __restrict__ rp, const I* __restrict__ ci,
+                                                      const T* __restrict__ val, T alpha, const T* __restrict__ x, T beta,
+                                                      T* __restrict__ y) {
+    const long long gid = (long long)blockIdx.x * BLK + threadIdx.x;
+    const long long row = gid >> 3;
+    const int l = threadIdx.x & 7;
+    if (row >= nrow) return;
+    double acc = 0.0;
+    for (int k = rp[row] + l; k < rp[row + 1]; k += 8) acc += val[k] * x[ci[k]];
+    acc += __shfl_xor(acc, 1, WAVE);
+    acc += __shfl_xor(acc, 2, WAVE);
+    acc += __shfl_xor(acc, 4, WAVE);
+    if (l == 0) y[row] = (beta == 0.0) ? alpha * acc : alpha * acc + beta * y[row];
+}
+
+__device__ __forceinline__ int find_diag(const I* __restrict__ rp, const I* __restrict__ ci, int node) {
+    int lo = rp[node], hi = rp[node + 1] - 1;  // col_ind sorted ascending per row (csr.c:57-79)
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (ci[mid] < node) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// closed-form inverse of a 3x3 given row-major m; returns inverse row-major
+__device__ __forceinline__ void inv3(const double* m, double* o) {
+    const double c00 = m[4] * m[8] - m[5] * m[7];
+    const double c01 = m[5] * m[6] - m[3] * m[8];
+    const double c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id;
+    o[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id;
+    o[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id;
+    o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+// PCJacobiSetup (pc.c:44-85): the reference extracts D row-major, hands the 9
+// numbers to column-major LAPACK (=> inverts D^T) and keeps the column-major
+// result.  Memory image = inv(D^T) column-major = inv(D) row-major.
+__global__ __launch_bounds__(BLK) void pc_setup_kernel(I N, const I* rp, const I* ci, const T* val, T* dinv33, T* dinv1) {
+    const int node = blockIdx.x * BLK + threadIdx.x;
+    if (node >= N) return;
+    const int k = find_diag(rp, ci, node);
+    const T* b = val + (long long)k * 16;
+    double m[9], o[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m[r * 3 + c] = b[r * 4 + c];
+    inv3(m, o);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dinv33[(long long)node * 9 + i] = o[i];  // inv(D) row-major == inv(D^T) col-major
+    dinv1[node] = 1.0 / b[15];
+}
+
+// PCDecompositionApply (pc.c:136-147): z_u = inv(D)^T r_u (Q7), z_p = r_p * dinv1, tail copied.
+template <bool SCALED>
+__global__ __launch_bounds__(BLK) void pc_apply_kernel(I N, const T* __restrict__ dinv33, const T* __restrict__ dinv1,
+                                                      const T* __restrict__ x, const T* __restrict__ d_nrm, T* __restrict__ q,
+                                                      T* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    const double s = SCALED ? 1.0 / d_nrm[0] : 1.0;
+    if (i < N) {
+        const T* A = dinv33 + i * 9;  // column-major image: A(r,c) = A[r + 3c]
+        double x0 = x[3 * i], x1 = x[3 * i + 1], x2 = x[3 * i + 2], xp = x[3LL * N + i];
+        if (SCALED) {
+            x0 *= s; x1 *= s; x2 *= s; xp *= s;
+            q[3 * i] = x0; q[3 * i + 1] = x1; q[3 * i + 2] = x2; q[3LL * N + i] = xp;
+        }
+        y[3 * i + 0] = A[0] * x0 + A[3] * x1 + A[6] * x2;
+        y[3 * i + 1] = A[1] * x0 + A[4] * x1 + A[7] * x2;
+        y[3 * i + 2] = A[2] * x0 + A[5] * x1 + A[8] * x2;
+        y[3LL * N + i] = xp * dinv1[i];
+    }
+}
+
+// PCNone sections (phi, T): plain copy, optionally with the same normalisation
+__global__ __launch_bounds__(BLK) void tail_copy_kernel(long long begin, long long n, const T* x, const T* d_nrm, T* q, T* y) {
+    const long long i = begin + (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    double v = x[i];
+    if (d_nrm) { v *= 1.0 / d_nrm[0]; q[i] = v; }
+    y[i] = v;
+}
+
+__global__ __launch_bounds__(BLK) void block3_invert_kernel(I N, T* d) {
+    const int node = blockIdx.x * BLK + threadIdx.x;
+    if (node >= N) return;
+    double m[9], o[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = d[(long long)node * 9 + i];
+    inv3(m, o);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[(long long)node * 9 + i] = o[i];
+}
+
+// cublasDgemvStridedBatched(OP_N) on the column-major image (pc.c:104-112)
+__global__ __launch_bounds__(BLK) void block3_apply_kernel(I N, const T* __restrict__ dinv, const T* __restrict__ x, T* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= N) return;
+    const T* A = dinv + i * 9;
+    const double x0 = x[3 * i], x1 = x[3 * i + 1], x2 = x[3 * i + 2];
+    y[3 * i + 0] = A[0] * x0 + A[3] * x1 + A[6] * x2;
+    y[3 * i + 1] = A[1] * x0 + A[4] * x1 + A[7] * x2;
+    y[3 * i + 2] = A[2] * x0 + A[5] * x1 + A[8] * x2;
+}
+
+__global__ __launch_bounds__(BLK) void get_diag_kernel(I N, const I* rp, const I* ci, const T* val, T* d33, T* dp, T* du) {
+    const int node = blockIdx.x * BLK + threadIdx.x;
+    if (node >= N) return;
+    const int k = find_diag(rp, ci, node);
+    const T* b = val + (long long)k * 16;
+    if (d33)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) d33[(long long)node * 9 + r * 3 + c] = b[r * 4 + c];
+    if (dp) dp[node] = b[15];
+    if (du)
+        for (int r = 0; r < 3; ++r) du[(long long)node * 3 + r] = b[r * 4 + r];
+}
+
+// one thread per (nodal nonzero, entry)
+template <bool EXPORT>
+__global__ __launch_bounds__(BLK) void convert_kernel(I N, const I* __restrict__ rp, T* __restrict__ val, T* A00, T* A01,
+                                                     T* A10, T* A11) {
+    const int node = blockIdx.x;
+    const int start = rp[node], len = rp[node + 1] - start;
+    for (int t = threadIdx.x; t < len * 16; t += BLK) {
+        const int kk = t >> 4, e = t & 15, r = e >> 2, c = e & 3;
+        T* blk = val + ((long long)(start + kk)) * 16 + e;
+        T* dst;
+        if (r < 3 && c < 3) dst = A00 + (long long)start * 9 + (long long)r * len * 3 + kk * 3 + c;  // csr_impl.cu:24-59
+        else if (r < 3) dst = A01 + (long long)start * 3 + (long long)r * len + kk;
+        else if (c < 3) dst = A10 + (long long)start * 3 + kk * 3 + c;
+        else dst = A11 + start + kk;
+        if (EXPORT) *dst = *blk; else *blk = *dst;
+    }
+}
+
+__global__ __launch_bounds__(BLK) void dirichlet_vec_kernel(T* b, I n, const I* bnode, I shape, I comp) {
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    b[(long long)bnode[i] * shape + comp] = 0.0;
+}
+
+// MatrixFSZeroRow on the block layout: A00 row <- diag * delta, A01 row <- 0
+// (matrix.c:449-469, matrix_impl.cu:6-23).  8 lanes per boundary node.
+__global__ __launch_bounds__(BLK) void zero_rows_kernel(I N, const I* rp, const I* ci, T* val, I n, const I* bnode, I comp,
+                                                       T diag) {
+    const long long gid = (long long)blockIdx.x * BLK + threadIdx.x;
+    const int i = (int)(gid >> 3), l = threadIdx.x & 7;
+    if (i >= n) return;
+    const int node = bnode[i];
+    if (node < 0 || node >= N) return;
+    for (int k = rp[node] + l; k < rp[node + 1]; k += 8) {
+        T* b = val + (long long)k * 16 + comp * 4;
+        const bool isdiag = (ci[k] == node);
+        b[0] = (isdiag && comp == 0) ? diag : 0.0;
+        b[1] = (isdiag && comp == 1) ? diag : 0.0;
+        b[2] = (isdiag && comp == 2) ? diag : 0.0;
+        b[3] = 0.0;
+    }
+}
+
+// ---- reference-layout launchers (same symbols as matrix_impl.h / dirichlet.c) ----
+__global__ void ref_zero_row_kernel(T* matval, I num_row, const I* rp, const I* ci, I n, const I* row, I shift, T diag) {
+    int i = blockDim.x * blockIdx.x + threadIdx.x;
+    if (i >= n) return;
+    I ir = shift + row[i];
+    if (ir < 0 || ir >= num_row) return;
+    for (I j = rp[ir]; j < rp[ir + 1]; ++j) matval[j] = diag * (T)(ci[j] == ir);
+}
+__global__ void ref_get_diag_kernel(const T* val, const I* rp, const I* ci, T* diag, I num_row) {
+    int i = blockDim.x * blockIdx.x + threadIdx.x;
+    if (i >= num_row) return;
+    for (I j = rp[i]; j < rp[i + 1]; ++j)
+        if (ci[j] == i) { diag[i] = val[j]; break; }
+}
+__global__ void ref_get_diag_block_kernel(const T* matval, I bs, I num_row, const I* rp, const I* ci, T* out, int lda, int stride) {
+    int idx = blockDim.x * blockIdx.x + threadIdx.x;
+    if (idx >= num_row) return;
+    I start = rp[idx], end = rp[idx + 1], len = end - start, k;
+    for (k = start; k < end; ++k) if (ci[k] == idx) break;
+    const T* m = matval + (long long)start * bs * bs + (long long)(k - start) * bs;
+    T* d = out + (long long)idx * stride;
+    for (I i = 0; i < bs; ++i)
+        for (I j = 0; j < bs; ++j) d[i * lda + j] = m[(long long)i * len * bs + j];
+}
+__global__ void row_from_node_kernel(I n, I* row, I shape, I init) {
+    int i = blockDim.x * blockIdx.x + threadIdx.x;
+    if (i < n) row[i] = row[i] * shape + init;
+}
+__global__ void node_from_row_kernel(I n, I* node, I shape) {
+    int i = blockDim.x * blockIdx.x + threadIdx.x;
+    if (i < n) node[i] = node[i] / shape;
+}
+
+}  // namespace
+
+extern "C" {
+
+void dfl_bcsr_spmv(I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
+    if (N <= 0) return;
+    const int grid = ceil_div((long long)N * 8, BLK);
+    if (beta == 0.0) bcsr_spmv_kernel<true><<<grid, BLK, 0, S(stream)>>>(N, rp, ci, val, alpha, x, beta, y);
+    else bcsr_spmv_kernel<false><<<grid, BLK, 0, S(stream)>>>(N, rp, ci, val, alpha, x, beta, y);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_csr_spmv(I nrow, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
+    if (nrow <= 0) return;
+    csr_spmv_kernel<<<ceil_div((long long)nrow * 8, BLK), BLK, 0, S(stream)>>>(nrow, rp, ci, val, alpha, x, beta, y);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_pc_jacobi_setup(I N, const I* rp, const I* ci, const T* val, T* dinv33, T* dinv1, void* stream) {
+    pc_setup_kernel<<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, rp, ci, val, dinv33, dinv1);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_pc_jacobi_apply(I N, I n, const T* dinv33, const T* dinv1, const T* x, T* y, void* stream) {
+    pc_apply_kernel<false><<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, dinv33, dinv1, x, nullptr, nullptr, y);
+    if (n > 4 * N)
+        tail_copy_kernel<<<ceil_div((long long)n - 4LL * N, BLK), BLK, 0, S(stream)>>>(4LL * N, n, x, nullptr, nullptr, y);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_pc_jacobi_apply_scaled(I N, I n, const T* dinv33, const T* dinv1, const T* w, const T* d_nrm, T* q_out, T* y,
+                                void* stream) {
+    pc_apply_kernel<true><<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, dinv33, dinv1, w, d_nrm, q_out, y);
+    if (n > 4 * N)
+        tail_copy_kernel<<<ceil_div((long long)n - 4LL * N, BLK), BLK, 0, S(stream)>>>(4LL * N, n, w, d_nrm, q_out, y);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_block3_invert(I N, T* diag33, void* stream) {
+    block3_invert_kernel<<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, diag33);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_block3_apply(I N, const T* dinv33, const T* x, T* y, void* stream) {
+    block3_apply_kernel<<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, dinv33, x, y);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_bcsr_get_diag(I N, const I* rp, const I* ci, const T* val, T* d33, T* dp, T* du, void* stream) {
+    get_diag_kernel<<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, rp, ci, val, d33, dp, du);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_block_export_fs(I N, const I* rp, const T* val, T* A00, T* A01, T* A10, T* A11, void* stream) {
+    convert_kernel<true><<<N, BLK, 0, S(stream)>>>(N, rp, const_cast<T*>(val), A00, A01, A10, A11);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_block_import_fs(I N, const I* rp, T* val, const T* A00, const T* A01, const T* A10, const T* A11, void* stream) {
+    convert_kernel<false><<<N, BLK, 0, S(stream)>>>(N, rp, val, const_cast<T*>(A00), const_cast<T*>(A01), const_cast<T*>(A10),
+                                                   const_cast<T*>(A11));
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_dirichlet_vec(T* b, I n, const I* bnode, I shape, I comp, void* stream) {
+    if (n <= 0) return;
+    dirichlet_vec_kernel<<<ceil_div(n, BLK), BLK, 0, S(stream)>>>(b, n, bnode, shape, comp);
+    DFL_LAUNCH_CHECK();
+}
+void ApplyBCVecNodalGPU(T* b, I n, const I* bc_node, I shape, I init) { dfl_dirichlet_vec(b, n, bc_node, shape, init, nullptr); }
+
+void dfl_bcsr_zero_rows(I N, const I* rp, const I* ci, T* val, I n, const I* bnode, I comp, T diag, void* stream) {
+    if (n <= 0) return;
+    zero_rows_kernel<<<ceil_div((long long)n * 8, BLK), BLK, 0, S(stream)>>>(N, rp, ci, val, n, bnode, comp, diag);
+    DFL_LAUNCH_CHECK();
+}
+
+void MatrixCSRZeroRowGPU(T* matval, I num_row, I num_col, const I* rp, const I* ci, I n, const I* row, I shift, T diag) {
+    (void)num_col;
+    if (n <= 0) return;  // the reference launches with a negative n for the pressure block-row (matrix.c:464)
+    ref_zero_row_kernel<<<ceil_div(n, BLK), BLK>>>(matval, num_row, rp, ci, n, row, shift, diag);
+    DFL_LAUNCH_CHECK();
+}
+void MatrixCSRGetDiagGPU(const T* val, const I* rp, const I* ci, T* diag, I num_row) {
+    ref_get_diag_kernel<<<ceil_div(num_row, BLK), BLK>>>(val, rp, ci, diag, num_row);
+    DFL_LAUNCH_CHECK();
+}
+void MatrixGetDiagBlockGPU(const T* matval, I bs, I num_row, I num_col, const I* rp, const I* ci, T* out, int lda, int stride) {
+    (void)num_col;
+    ref_get_diag_block_kernel<<<ceil_div(num_row, BLK), BLK>>>(matval, bs, num_row, rp, ci, out, lda, stride);
+    DFL_LAUNCH_CHECK();
+}
+void GetRowFromNodeGPU(I n, I* row, I shape, I init) {
+    if (n <= 0) return;
+    row_from_node_kernel<<<ceil_div(n, BLK), BLK>>>(n, row, shape, init);
+    DFL_LAUNCH_CHECK();
+}
+void GetNodeFromRowGPU(I n, I* node, I shape) {
+    if (n <= 0) return;
+    node_from_row_kernel<<<ceil_div(n, BLK), BLK>>>(n, node, shape);
+    DFL_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,369 @@
+// One-time setup kernels: vertex->element map, XORWOW priorities, Jones-Plassmann-
+// Luby coloring, color batches, nodal sparsity pattern, pattern expansion.
+// Reference: src/color_impl.cu:17-255, src/indexing.cu:92-102, src/Mesh.c:165-206,
+// src/csr.c:81-190 (host algorithm there; on the device here), src/csr_impl.cu:24-59.
+// rocPRIM is used for the one-time scan / stable sort / select only.
+#include "dfl_common.hpp"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <rocrand/rocrand_xorwow.h>
+#include <climits>
+#include <vector>
+
+namespace {
+
+constexpr int BLK = 256;
+
+__global__ void v2e_count_kernel(const I* ien, I T_, I* row_ptr) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= T_) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(row_ptr + ien[i * 4 + j] + 1, 1);
+}
+
+__global__ void v2e_fill_kernel(const I* ien, I T_, const I* row_ptr, I* col, I* counter) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= T_) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const I node = ien[i * 4 + j];
+        const int off = atomicAdd(counter + node, 1);
+        col[row_ptr[node] + off] = (I)i;
+    }
+}
+
+// cuRAND XORWOW host-API stream in LEGACY ordering: value n comes from
+// subsequence n % 4096 (2^67 apart), position n / 4096.  One thread per subsequence.
+__global__ void xorwow_legacy_kernel(unsigned long long seed, I n, unsigned int* out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= 4096 || s >= n) return;
+    rocrand_device::xorwow_engine eng(seed, (unsigned long long)s, 0ULL);
+    for (long long i = s; i < n; i += 4096) out[i] = eng.next();
+}
+
+// GenerateRandomColorFunctor, color_impl.cu:185-192: val % (ub - lb) + lb, ub = INT_MAX/2
+__global__ void priority_mod_kernel(I n, I* color) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int v = (unsigned int)color[i];
+    color[i] = (I)(v % (unsigned int)(INT_MAX / 2));
+}
+
+// ColorElementJPLKernel (color_impl.cu:64-95), synchronous form: local maxima among the
+// still-uncolored vertex neighbours.  Equal priorities are ordered by element id (Q1):
+// identical to the reference whenever the mesh is tie-free.
+__global__ void jpl_mark_kernel(const I* __restrict__ ien, const I* __restrict__ rp, const I* __restrict__ ci,
+                                const I* __restrict__ color, I T_, unsigned char* __restrict__ is_max) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= T_) return;
+    const I ec = color[i];
+    if (ec < 0) { is_max[i] = 0; return; }
+    bool found_max = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const I node = ien[i * 4 + j];
+        for (I k = rp[node]; k < rp[node + 1]; ++k) {
+            const I el = ci[k];
+            if (el == i) continue;
+            const I oc = color[el];
+            if (ec < oc || (ec == oc && i < el)) found_max = false;
+        }
+    }
+    is_max[i] = found_max ? 1 : 0;
+}
+
+// ReverseColorKernel + SetUpFlagKernel + cub Max (color_impl.cu:120-134,163-177)
+__global__ void jpl_commit_kernel(I* color, const unsigned char* is_max, I c_rev, I T_, int* left) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= T_) return;
+    if (is_max[i]) color[i] = c_rev;
+    else if (color[i] >= 0) *left = 1;  // benign same-value race
+}
+
+__global__ void recover_color_kernel(I* color, I T_) {  // color_impl.cu:136-141
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i < T_) color[i] = color[i] * (-1) - 1;
+}
+
+__global__ void max_kernel(const I* x, I n, I* out) {
+    I m = INT_MIN;
+    for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) m = max(m, x[i]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, WAVE));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+__global__ void count_value_kernel(const I* x, I n, I value, I* out) {
+    I c = 0;
+    for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long long)gridDim.x * BLK) c += (x[i] == value);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, WAVE);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+__global__ void histogram_kernel(const I* color, I T_, I* hist /*256*/) {
+    __shared__ int sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * BLK + threadIdx.x; i < T_; i += (long long)gridDim.x * BLK) {
+        const I c = color[i];
+        if (c >= 0 && c < 256) atomicAdd(&sh[c], 1);
+    }
+    __syncthreads();
+    if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+__global__ void iota_kernel(I n, I* x) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i < n) x[i] = (I)i;
+}
+
+__global__ void tie_count_kernel(const I* ien, I T_, const I* rp, const I* ci, const I* prio, unsigned long long* out) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= T_) return;
+    int ties = 0;
+    for (int j = 0; j < 4; ++j) {
+        const I node = ien[i * 4 + j];
+        for (I k = rp[node]; k < rp[node + 1]; ++k) {
+            const I el = ci[k];
+            if (el > i && prio[el] == prio[i]) ++ties;  // a pair sharing several vertices is counted per shared vertex
+        }
+    }
+    if (ties) atomicAdd(out, (unsigned long long)ties);
+}
+
+// ---- nodal pattern: sorted unique neighbours per node, <= 64 (csr.c:10,57-79) -----
+constexpr int PREALLOC = 64;
+
+__device__ int node_neighbours(I node, const I* __restrict__ ien, const I* __restrict__ rp, const I* __restrict__ ci, I* list,
+                               bool* overflow) {
+    int len = 0;
+    for (I k = rp[node]; k < rp[node + 1]; ++k) {
+        const long long el = ci[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const I v = ien[el * 4 + j];
+            int lo = 0, hi = len;  // lower_bound
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (list[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            if (lo < len && list[lo] == v) continue;
+            if (len >= PREALLOC) { *overflow = true; continue; }
+            for (int m = len; m > lo; --m) list[m] = list[m - 1];
+            list[lo] = v;
+            ++len;
+        }
+    }
+    return len;
+}
+
+__global__ __launch_bounds__(64) void pattern_count_kernel(I N, const I* ien, const I* rp, const I* ci, I* row_len, I* d_overflow) {
+    const int node = blockIdx.x * 64 + threadIdx.x;
+    if (node >= N) return;
+    I list[PREALLOC];
+    bool ov = false;
+    row_len[node] = node_neighbours(node, ien, rp, ci, list, &ov);
+    if (ov) *d_overflow = 1;
+}
+
+__global__ __launch_bounds__(64) void pattern_fill_kernel(I N, const I* ien, const I* rp, const I* ci, const I* row_ptr, I* col_ind) {
+    const int node = blockIdx.x * 64 + threadIdx.x;
+    if (node >= N) return;
+    I list[PREALLOC];
+    bool ov = false;
+    const int len = node_neighbours(node, ien, rp, ci, list, &ov);
+    I* dst = col_ind + row_ptr[node];
+    for (int i = 0; i < len; ++i) dst[i] = list[i];
+}
+
+// SetRowLength + SetColIndex, csr_impl.cu:24-59
+__global__ void expand_kernel(I N, const I* rp, const I* ci, I br, I bc, I* nrp, I* nci) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= N) return;
+    const I start = rp[i], len = rp[i + 1] - start;
+    for (I j = 0; j < br; ++j) {
+        const I base = start * br * bc + j * bc * len;
+        nrp[i * br + j] = base;
+        for (I k = 0; k < len; ++k)
+            for (I l = 0; l < bc; ++l) nci[base + k * bc + l] = ci[start + k] * bc + l;
+    }
+    if (i == N - 1) nrp[(long long)N * br] = rp[N] * br * bc;  // Q3: entry the reference never writes
+}
+
+__global__ void scan_tail_kernel(const I* len, I* ptr, I n) { ptr[n] = ptr[n - 1] + len[n - 1]; }
+
+struct EqFlag {
+    const I* data;
+    I value;
+    __device__ bool operator()(I i) const { return data[i] == value; }
+};
+
+}  // namespace
+
+extern "C" {
+
+int64_t dfl_scan_temp_bytes(I n) {
+    size_t bytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, bytes, (const I*)nullptr, (I*)nullptr, (I)0, (size_t)n, rocprim::plus<I>());
+    return (int64_t)bytes + 16;
+}
+
+void dfl_exclusive_scan_i32(I n, const I* len, I* ptr, void* temp, int64_t temp_bytes, void* stream) {
+    // ptr[0..n] : exclusive scan of len[0..n-1] plus the total at ptr[n]
+    size_t bytes = (size_t)temp_bytes;
+    DFL_GUARD(hipMemsetAsync(ptr + n, 0, sizeof(I), S(stream)));
+    DFL_GUARD(rocprim::exclusive_scan(temp, bytes, len, ptr, (I)0, (size_t)n, rocprim::plus<I>(), S(stream)));
+    // total = ptr[n-1] + len[n-1]
+    if (n > 0) scan_tail_kernel<<<1, 1, 0, S(stream)>>>(len, ptr, n);
+    DFL_LAUNCH_CHECK();
+}
+
+void GenerateV2EMapRowTetGPU(const I* ien, I T_, I N, I* row_ptr) {
+    DFL_GUARD(hipMemset(row_ptr, 0, sizeof(I) * (size_t)(N + 1)));
+    v2e_count_kernel<<<ceil_div(T_, BLK), BLK>>>(ien, T_, row_ptr);
+    size_t bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, bytes, row_ptr, row_ptr, (size_t)(N + 1), rocprim::plus<I>());
+    void* tmp = nullptr;
+    DFL_GUARD(hipMalloc(&tmp, bytes + 16));
+    DFL_GUARD(rocprim::inclusive_scan(tmp, bytes, row_ptr, row_ptr, (size_t)(N + 1), rocprim::plus<I>()));
+    DFL_GUARD(hipDeviceSynchronize());
+    DFL_GUARD(hipFree(tmp));
+}
+
+void GenerateV2EMapColTetGPU(const I* ien, I T_, I N, const I* row_ptr, I* col_idx) {
+    I* counter = nullptr;
+    DFL_GUARD(hipMalloc((void**)&counter, sizeof(I) * (size_t)N));
+    DFL_GUARD(hipMemset(counter, 0, sizeof(I) * (size_t)N));
+    v2e_fill_kernel<<<ceil_div(T_, BLK), BLK>>>(ien, T_, row_ptr, col_idx, counter);
+    DFL_GUARD(hipDeviceSynchronize());
+    DFL_GUARD(hipFree(counter));
+}
+
+void GenerateRandomColor(I* color, I n, I max_color) {
+    if (n <= 0) return;
+    xorwow_legacy_kernel<<<4096 / 64, 64>>>(1234ULL, n, reinterpret_cast<unsigned int*>(color));
+    if (max_color != 0) priority_mod_kernel<<<ceil_div(n, BLK), BLK>>>(n, color);
+    DFL_LAUNCH_CHECK();
+}
+
+void ColorElementJPLTetGPU(const I* ien, const I* rp, const I* ci, I max_color, I* color, I T_) {
+    GenerateRandomColor(color, T_, max_color);
+    unsigned char* is_max = nullptr;
+    int* d_left = nullptr;
+    DFL_GUARD(hipMalloc((void**)&is_max, (size_t)T_));
+    DFL_GUARD(hipMalloc((void**)&d_left, sizeof(int)));
+    const int grid = ceil_div(T_, BLK);
+    int left = 1;
+    I c = 0;
+    for (; c < max_color && left; ++c) {
+        DFL_GUARD(hipMemsetAsync(d_left, 0, sizeof(int), 0));
+        jpl_mark_kernel<<<grid, BLK>>>(ien, rp, ci, color, T_, is_max);
+        jpl_commit_kernel<<<grid, BLK>>>(color, is_max, -1 - c, T_, d_left);
+        DFL_GUARD(hipMemcpy(&left, d_left, sizeof(int), hipMemcpyDeviceToHost));
+    }
+    recover_color_kernel<<<grid, BLK>>>(color, T_);
+    DFL_GUARD(hipDeviceSynchronize());
+    DFL_GUARD(hipFree(is_max));
+    DFL_GUARD(hipFree(d_left));
+}
+
+void GetMaxColorGPU(const I* color, I n, I* h_max) {
+    I* d = nullptr;
+    DFL_GUARD(hipMalloc((void**)&d, sizeof(I)));
+    I init = INT_MIN;
+    DFL_GUARD(hipMemcpy(d, &init, sizeof(I), hipMemcpyHostToDevice));
+    int g = ceil_div(n, BLK * 8);
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    max_kernel<<<g, BLK>>>(color, n, d);
+    DFL_GUARD(hipMemcpy(h_max, d, sizeof(I), hipMemcpyDeviceToHost));
+    DFL_GUARD(hipFree(d));
+}
+
+I CountValueColorLegacy(const I* data, I n, I value) {
+    I* d = nullptr;
+    I h = 0;
+    DFL_GUARD(hipMalloc((void**)&d, sizeof(I)));
+    DFL_GUARD(hipMemset(d, 0, sizeof(I)));
+    int g = ceil_div(n, BLK * 8);
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    count_value_kernel<<<g, BLK>>>(data, n, value, d);
+    DFL_GUARD(hipMemcpy(&h, d, sizeof(I), hipMemcpyDeviceToHost));
+    DFL_GUARD(hipFree(d));
+    return h;
+}
+
+void FindValueColor(const I* data, I n, I value, I* result) {
+    // thrust::copy_if over a counting iterator (indexing.cu:65-77): stable
+    rocprim::counting_iterator<I> first(0);
+    EqFlag pred{data, value};
+    size_t bytes = 0;
+    I* d_count = nullptr;
+    DFL_GUARD(hipMalloc((void**)&d_count, sizeof(I)));
+    (void)rocprim::select(nullptr, bytes, first, result, d_count, (size_t)n, pred);
+    void* tmp = nullptr;
+    DFL_GUARD(hipMalloc(&tmp, bytes + 16));
+    DFL_GUARD(rocprim::select(tmp, bytes, first, result, d_count, (size_t)n, pred));
+    DFL_GUARD(hipDeviceSynchronize());
+    DFL_GUARD(hipFree(tmp));
+    DFL_GUARD(hipFree(d_count));
+}
+
+void dfl_color_batches(const I* color, I T_, I num_color, I* h_batch_offset, I* batch_ind) {
+    // counts
+    I* d_hist = nullptr;
+    DFL_GUARD(hipMalloc((void**)&d_hist, 256 * sizeof(I)));
+    DFL_GUARD(hipMemset(d_hist, 0, 256 * sizeof(I)));
+    int g = ceil_div(T_, BLK * 16);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    histogram_kernel<<<g, BLK>>>(color, T_, d_hist);
+    I hist[256];
+    DFL_GUARD(hipMemcpy(hist, d_hist, sizeof hist, hipMemcpyDeviceToHost));
+    h_batch_offset[0] = 0;
+    for (I c = 0; c < num_color; ++c) h_batch_offset[c + 1] = h_batch_offset[c] + (c < 256 ? hist[c] : 0);
+    // stable sort of element ids by color (8 key bits) == per-color ascending lists
+    unsigned int *keys_out = nullptr;
+    I* vals_in = nullptr;
+    DFL_GUARD(hipMalloc((void**)&keys_out, sizeof(unsigned int) * (size_t)T_));
+    DFL_GUARD(hipMalloc((void**)&vals_in, sizeof(I) * (size_t)T_));
+    iota_kernel<<<ceil_div(T_, BLK), BLK>>>(T_, vals_in);
+    size_t bytes = 0;
+    const unsigned int* keys_in = reinterpret_cast<const unsigned int*>(color);
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, batch_ind, (size_t)T_, 0, 8);
+    void* tmp = nullptr;
+    DFL_GUARD(hipMalloc(&tmp, bytes + 16));
+    DFL_GUARD(rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, batch_ind, (size_t)T_, 0, 8));
+    DFL_GUARD(hipDeviceSynchronize());
+    DFL_GUARD(hipFree(tmp));
+    DFL_GUARD(hipFree(keys_out));
+    DFL_GUARD(hipFree(vals_in));
+    DFL_GUARD(hipFree(d_hist));
+}
+
+I dfl_count_priority_ties(const I* ien, I T_, const I* rp, const I* ci, const I* prio) {
+    unsigned long long* d = nullptr;
+    unsigned long long h = 0;
+    DFL_GUARD(hipMalloc((void**)&d, sizeof(unsigned long long)));
+    DFL_GUARD(hipMemset(d, 0, sizeof(unsigned long long)));
+    tie_count_kernel<<<ceil_div(T_, BLK), BLK>>>(ien, T_, rp, ci, prio, d);
+    DFL_GUARD(hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost));
+    DFL_GUARD(hipFree(d));
+    return (I)h;
+}
+
+void dfl_pattern_count(I N, const I* ien, const I* rp, const I* ci, I* row_len, I* d_overflow, void* stream) {
+    pattern_count_kernel<<<ceil_div(N, 64), 64, 0, S(stream)>>>(N, ien, rp, ci, row_len, d_overflow);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_pattern_fill(I N, const I* ien, const I* rp, const I* ci, const I* row_ptr, I* col_ind, void* stream) {
+    pattern_fill_kernel<<<ceil_div(N, 64), 64, 0, S(stream)>>>(N, ien, rp, ci, row_ptr, col_ind);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_csr_expand(I N, const I* rp, const I* ci, I br, I bc, I* nrp, I* nci, void* stream) {
+    expand_kernel<<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, rp, ci, br, bc, nrp, nci);
+    DFL_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+/* AssembleSystemTet / AssembleSystemTetFace (src/assemble.h:13-14) and their caller
+ * AssembleSystem (src/main.c:31-75): the color-batch loop of src/assemble.cu:1559-1738
+ * with one fused launch per color, no per-call device allocation (the reference
+ * mallocs+memsets+frees nine work buffers per call, :1533-1553,1746-1760). */
+#include <string.h>
+#include "dedflow.h"
+#include "dedflow_kernels.h"
+#include "host_private.h"
+
+#define BS (6)
+static b32 g_quiet = FALSE;
+void DflSetQuiet(b32 quiet) { g_quiet = quiet; }
+b32 DflQuiet(void) { return g_quiet; }
+
+static const CSRAttr* block_pattern(Matrix* J, value_type** val) {
+    *val = MatrixFSBlockValues(J);
+    if (!*val) {
+        fprintf(stderr, "AssembleSystemTet: J must be the (u,p) field-split matrix of src/main.c:374-391 after MatrixSetup\n");
+        ASSERT(FALSE);
+        return NULL;
+    }
+    return ((MatrixFS*)J->data)->spy1x1;
+}
+
+/* (elem,a,b) -> nonzero map for this pattern, batch order; built once per (mesh, pattern) */
+static void ensure_nzmap(Mesh3D* mesh, const CSRAttr* spy) {
+    MeshExt* x = (MeshExt*)mesh->ext;
+    if (x->nzmap_b && x->nzmap_attr == spy) return;
+    CdamFreeDevice(x->nzmap_b, 0);
+    x->nzmap_b = (index_type*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(index_type));
+    dfl_elem_nzmap(mesh->num_tet, x->ien_b, spy->row_ptr, spy->col_ind, x->nzmap_b, DflStream());
+    x->nzmap_attr = spy;
+}
+
+void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J) {
+    MeshExt* x = (MeshExt*)mesh->ext;
+    const Mesh3DData* dev = Mesh3DDevice(mesh);
+    const index_type N = Mesh3DNumNode(mesh);
+    hipStream_t s = DflStream();
+    ASSERT((F || J) && "Either F or J should be provided");
+    ASSERT(x && x->ien_b && "Mesh3DGenerateColorBatch must run before assembly");
+    if (!g_quiet) printf("Assemble: %s %s\n", F ? "F" : "", J ? "J" : "");
+    value_type* val = NULL;
+    const CSRAttr* spy = NULL;
+    if (J) {
+        spy = block_pattern(J, &val);
+        ensure_nzmap(mesh, spy);
+    }
+    for (index_type b = 0; b < mesh->num_batch; ++b) {
+        const index_type off = mesh->batch_offset[b];
+        const index_type bsz = mesh->batch_offset[b + 1] - off;
+        if (bsz == 0) break; /* assemble.cu:1565-1567 */
+        const index_type* ien_b = x->ien_b + (size_t)off * 4;
+        if (F) dfl_assemble_tet_rhs(bsz, ien_b, N, dev->xg, wgalpha_dptr, dwgalpha_dptr, F, s);
+        if (J) dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, dev->xg, wgalpha_dptr, val, s);
+    }
+}
+
+void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J) {
+    const index_type group = 4; /* assemble.cu:1826-1828 */
+    const Mesh3DData* dev = Mesh3DDevice(mesh);
+    const index_type N = Mesh3DNumNode(mesh);
+    hipStream_t s = DflStream();
+    if (mesh->num_bound <= group) return;
+    DflMeshPrepareFaces(mesh, group);
+    MeshExt* x = (MeshExt*)mesh->ext;
+    value_type* val = NULL;
+    const CSRAttr* spy = NULL;
+    if (J) spy = block_pattern(J, &val);
+    const index_type* f2e = Mesh3DBoundF2E(mesh, group);
+    const index_type* forn = Mesh3DBoundFORN(mesh, group);
+    for (index_type c = 0; c < mesh->num_color; ++c) { /* one launch per parent color: race-free, color order */
+        index_type lo = x->face_color_offset[c], nf = x->face_color_offset[c + 1] - lo;
+        if (!nf) continue;
+        dfl_assemble_face(nf, x->face_list + lo, f2e, forn, dev->ien, N, dev->xg, wgalpha_dptr, dwgalpha_dptr, F,
+                          spy ? spy->row_ptr : NULL, spy ? spy->col_ind : NULL, val, s);
+    }
+}
+
+void AssembleSystem(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, Dirichlet** bcs, index_type nbc) {
+    index_type num_node = Mesh3DNumNode(mesh);
+    hipStream_t s = DflStream();
+    if (F) HIPGUARD(hipMemsetAsync(F, 0, (size_t)num_node * sizeof(f64) * BS, s));
+    if (J) MatrixZero(J);
+    if (Mesh3DNumTet(mesh)) {
+        AssembleSystemTet(mesh, wgalpha, dwgalpha, F, J);
+        AssembleSystemTetFace(mesh, wgalpha, dwgalpha, F, J);
+    }
+    if (F) HIPGUARD(hipMemsetAsync(F + 4 * (size_t)num_node, 0, (size_t)num_node * sizeof(f64) * 2, s)); /* main.c:63-66 */
+    for (index_type ibc = 0; ibc < nbc; ++ibc) {
+        if (F) DirichletApplyVec(bcs[ibc], F);
+        if (J) DirichletApplyMat(bcs[ibc], J);
+    }
+}

@@ -1,0 +1,19 @@
+/* Library-private declarations shared by the host C files. */
+#ifndef DFL_HOST_PRIVATE_H
+#define DFL_HOST_PRIVATE_H
+#include "dedflow.h"
+
+typedef struct MeshExt {
+    index_type* ien_b;             /* device [T][4], elements in batch (color-major) order */
+    index_type* nzmap_b;           /* device [T][16], (elem,a,b) -> nodal nonzero, batch order */
+    const CSRAttr* nzmap_attr;     /* pattern the map was built for */
+    index_type face_group;         /* boundary group the face list below belongs to (-1: none) */
+    index_type* face_list;         /* device: faces of that group ordered by parent color */
+    index_type* face_color_offset; /* host [num_color+1] */
+    index_type* h_f2e;             /* host copy of bound_f2e */
+} MeshExt;
+
+void DflMeshPrepareFaces(Mesh3D* mesh, index_type group);
+b32 DflQuiet(void);
+
+#endif

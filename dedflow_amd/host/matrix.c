@@ -1,0 +1,318 @@
+/* Matrix objects behind the reference's Matrix / MatrixOp vtable (src/matrix.h:27-147).
+ *
+ * MAT_TYPE_CSR : scalar CSR in the reference layout, hand-written SpMV instead of
+ *                cusparseSpMV (src/matrix.c:101-165).
+ * MAT_TYPE_FS  : when the grid is the (u,p) 2x2 layout the reference driver builds
+ *                (src/main.c:374-391: offsets {0,3,4,..}, A00 3x3 / A01 3x1 / A10 1x3 /
+ *                A11 1x1 over one nodal pattern) the four sub-matrices are stored as ONE
+ *                array of 4x4 blocks ("block mode") and every operation is a single
+ *                launch; otherwise the reference's per-sub-matrix loop is used.
+ */
+#include <string.h>
+#include "dedflow.h"
+#include "dedflow_kernels.h"
+#include "host_private.h"
+
+#define MATRIX_CALL(mat, func, ...)                                                                          \
+    do {                                                                                                     \
+        if ((mat)->op->func) (mat)->op->func(mat, ##__VA_ARGS__);                                            \
+        else fprintf(stderr, "Matrix operation %s is not implemented for type: %d\n", #func, (mat)->type);   \
+    } while (0)
+
+/* =============================== CSR ================================================== */
+static MatrixCSR* csr_of(Matrix* m) { return (MatrixCSR*)m->data; }
+
+static value_type* csr_values(Matrix* m) {
+    MatrixCSR* c = csr_of(m);
+    if (!c->val) c->val = (value_type*)CdamMallocDevice((ptrdiff_t)c->attr->nnz * SIZE_OF(value_type));
+    return c->val;
+}
+
+static void csr_setup(Matrix* m) { UNUSED(m); }
+
+static void csr_zero(Matrix* m) {
+    MatrixCSR* c = csr_of(m);
+    if (c->owner && c->owner->block_mode) return; /* the parent zeroes the shared block storage */
+    HIPGUARD(hipMemsetAsync(csr_values(m), 0, (size_t)c->attr->nnz * sizeof(value_type), DflStream()));
+}
+
+static void csr_zero_row(Matrix* m, index_type n, const index_type* row, index_type shift, value_type diag) {
+    MatrixCSR* c = csr_of(m);
+    MatrixCSRZeroRowGPU(csr_values(m), c->attr->num_row, c->attr->num_col, c->attr->row_ptr, c->attr->col_ind, n, row, shift,
+                        diag);
+}
+
+static void csr_amvpby(Matrix* m, value_type alpha, value_type* x, value_type beta, value_type* y) {
+    MatrixCSR* c = csr_of(m);
+    dfl_csr_spmv(c->attr->num_row, c->attr->row_ptr, c->attr->col_ind, csr_values(m), alpha, x, beta, y, DflStream());
+}
+
+static void csr_amvpby_mask(Matrix* m, value_type alpha, value_type* x, value_type beta, value_type* y, value_type* lm,
+                            value_type* rm) {
+    MatrixCSR* c = csr_of(m);
+    value_type* input = x;
+    if (rm) {
+        input = (value_type*)CdamMallocDevice((ptrdiff_t)c->attr->num_col * SIZE_OF(value_type));
+        VecPointwiseMult(x, rm, input, c->attr->num_col);
+    }
+    csr_amvpby(m, alpha, input, beta, y);
+    if (lm) VecPointwiseMult(y, lm, y, c->attr->num_row);
+    if (rm) {
+        HIPGUARD(hipStreamSynchronize(DflStream()));
+        CdamFreeDevice(input, 0);
+    }
+}
+
+static void csr_matvec(Matrix* m, value_type* x, value_type* y) { csr_amvpby(m, 1.0, x, 0.0, y); }
+static void csr_matvec_mask(Matrix* m, value_type* x, value_type* y, value_type* lm, value_type* rm) {
+    csr_amvpby_mask(m, 1.0, x, 0.0, y, lm, rm);
+}
+
+static void csr_get_diag(Matrix* m, value_type* diag, index_type bs) {
+    MatrixCSR* c = csr_of(m);
+    const CSRAttr* attr = c->attr;
+    ASSERT(attr->num_row == attr->num_col && "Matrix is not square");
+    if (c->owner && c->owner->block_mode) { /* view into the block storage */
+        const CSRAttr* spy = c->owner->spy1x1;
+        index_type i = c->owner_slot / c->owner->n_offset;
+        if (i == 0 && bs == 3) dfl_bcsr_get_diag(spy->num_row, spy->row_ptr, spy->col_ind, c->owner->block_val, diag, NULL, NULL, DflStream());
+        else if (i == 0 && bs == 1) dfl_bcsr_get_diag(spy->num_row, spy->row_ptr, spy->col_ind, c->owner->block_val, NULL, NULL, diag, DflStream());
+        else if (i == 1 && bs == 1) dfl_bcsr_get_diag(spy->num_row, spy->row_ptr, spy->col_ind, c->owner->block_val, NULL, diag, NULL, DflStream());
+        else ASSERT(0 && "Block size is not compatible with the matrix size");
+        return;
+    }
+    if (bs == 1) MatrixCSRGetDiagGPU(csr_values(m), attr->row_ptr, attr->col_ind, diag, attr->num_row);
+    else if (bs > 1) {
+        ASSERT(attr->parent && attr->num_row == attr->parent->num_row * bs && "Block size is not compatible with the matrix size");
+        const CSRAttr* p = attr->parent;
+        MatrixGetDiagBlockGPU(csr_values(m), bs, p->num_row, p->num_col, p->row_ptr, p->col_ind, diag, bs, bs * bs);
+    } else ASSERT(0 && "Block size should be greater than 0");
+}
+
+static void csr_destroy(Matrix* m) {
+    MatrixCSR* c = csr_of(m);
+    CdamFreeDevice(c->val, 0);
+    CdamFreeHost(c, SIZE_OF(MatrixCSR));
+    CdamFreeHost(m, SIZE_OF(Matrix));
+}
+
+Matrix* MatrixCreateTypeCSR(const CSRAttr* attr, void* ctx) {
+    UNUSED(ctx);
+    Matrix* m = (Matrix*)CdamMallocHost(SIZE_OF(Matrix));
+    memset(m, 0, sizeof *m);
+    m->size[0] = attr->num_row;
+    m->size[1] = attr->num_col;
+    m->type = MAT_TYPE_CSR;
+    MatrixCSR* c = (MatrixCSR*)CdamMallocHost(SIZE_OF(MatrixCSR));
+    memset(c, 0, sizeof *c);
+    c->attr = attr;
+    m->data = c;
+    m->op->setup = csr_setup;
+    m->op->zero = csr_zero;
+    m->op->zero_row = csr_zero_row;
+    m->op->amvpby = csr_amvpby;
+    m->op->amvpby_mask = csr_amvpby_mask;
+    m->op->matvec = csr_matvec;
+    m->op->matvec_mask = csr_matvec_mask;
+    m->op->get_diag = csr_get_diag;
+    m->op->destroy = csr_destroy;
+    return m;
+}
+
+/* =============================== FS =================================================== */
+static MatrixFS* fs_of(Matrix* m) { return (MatrixFS*)m->data; }
+
+static b32 fs_is_up_layout(MatrixFS* fs) {
+    index_type n = fs->n_offset;
+    if (n < 2 || !fs->spy1x1) return FALSE;
+    if (fs->offset[0] != 0 || fs->offset[1] != 3 || fs->offset[2] != 4) return FALSE;
+    for (index_type i = 0; i < n; ++i)
+        for (index_type j = 0; j < n; ++j) {
+            Matrix* s = fs->mat[i * n + j];
+            b32 expect = (i < 2 && j < 2);
+            if (!expect) { if (s) return FALSE; continue; }
+            if (!s || s->type != MAT_TYPE_CSR) return FALSE;
+            const CSRAttr* a = csr_of(s)->attr;
+            index_type br = i == 0 ? 3 : 1, bc = j == 0 ? 3 : 1;
+            if (a->num_row != fs->spy1x1->num_row * br || a->num_col != fs->spy1x1->num_col * bc ||
+                a->nnz != fs->spy1x1->nnz * br * bc) return FALSE;
+        }
+    return TRUE;
+}
+
+static void fs_setup(Matrix* m) {
+    MatrixFS* fs = fs_of(m);
+    index_type n = fs->n_offset;
+    index_type num_row = fs->spy1x1->num_row, num_col = fs->spy1x1->num_col;
+    m->size[0] = fs->offset[n] * num_row; /* matrix.c:408-409 */
+    m->size[1] = fs->offset[n] * num_col;
+    for (index_type i = 0; i < n * n; ++i)
+        if (fs->mat[i]) MatrixSetup(fs->mat[i]);
+    fs->block_mode = fs_is_up_layout(fs);
+    if (fs->block_mode) {
+        if (!fs->block_val) fs->block_val = (value_type*)CdamMallocDevice((ptrdiff_t)fs->spy1x1->nnz * 16 * SIZE_OF(value_type));
+        for (index_type i = 0; i < 2; ++i)
+            for (index_type j = 0; j < 2; ++j) {
+                MatrixCSR* c = csr_of(fs->mat[i * n + j]);
+                c->owner = fs;
+                c->owner_slot = i * n + j;
+            }
+    } else {
+        value_type** matval = (value_type**)CdamMallocHost(SIZE_OF(value_type*) * n * n);
+        for (index_type i = 0; i < n * n; ++i) matval[i] = fs->mat[i] ? csr_values(fs->mat[i]) : NULL;
+        HIPGUARD(hipMemcpy(fs->d_matval, matval, sizeof(value_type*) * (size_t)(n * n), H2D));
+        CdamFreeHost(matval, 0);
+    }
+}
+
+static void fs_zero(Matrix* m) {
+    MatrixFS* fs = fs_of(m);
+    if (fs->block_mode) {
+        HIPGUARD(hipMemsetAsync(fs->block_val, 0, (size_t)fs->spy1x1->nnz * 16 * sizeof(value_type), DflStream()));
+        return;
+    }
+    for (index_type i = 0; i < fs->n_offset * fs->n_offset; ++i)
+        if (fs->mat[i]) MatrixZero(fs->mat[i]);
+}
+
+/* MatrixFSZeroRow, matrix.c:449-469.  `row` holds scalar rows node*3+ic of the velocity
+ * block; the pressure block-row call degenerates to a no-op in the reference (negative
+ * count) -- same here. */
+static void fs_zero_row(Matrix* m, index_type n, const index_type* row, index_type shift, value_type diag) {
+    MatrixFS* fs = fs_of(m);
+    index_type no = fs->n_offset, num_row = fs->spy1x1->num_row;
+    if (fs->block_mode) {
+        fprintf(stderr, "MatrixZeroRow on a block-mode FS matrix takes boundary NODES: use DirichletApplyMat\n");
+        UNUSED(n); UNUSED(row); UNUSED(shift); UNUSED(diag);
+        return;
+    }
+    for (index_type i = 0; i < no; ++i)
+        for (index_type j = 0; j < no; ++j) {
+            if (!fs->mat[i * no + j]) continue;
+            MatrixZeroRow(fs->mat[i * no + j], n - fs->offset[i] * num_row, row + fs->offset[i] * num_row,
+                          -num_row * fs->offset[i], i == j ? diag : 0.0);
+        }
+}
+
+static void fs_amvpby(Matrix* m, value_type alpha, value_type* x, value_type beta, value_type* y) {
+    MatrixFS* fs = fs_of(m);
+    index_type no = fs->n_offset, num_row = fs->spy1x1->num_row, num_col = fs->spy1x1->num_col;
+    if (fs->block_mode) { /* scal(4N) + 4 SpMV of matrix.c:471-497 in one launch */
+        dfl_bcsr_spmv(num_row, fs->spy1x1->row_ptr, fs->spy1x1->col_ind, fs->block_val, alpha, x, beta, y, DflStream());
+        return;
+    }
+    dfl_dscal(no * num_row, beta, y, DflStream());
+    for (index_type i = 0; i < no; ++i)
+        for (index_type j = 0; j < no; ++j)
+            if (fs->mat[i * no + j])
+                MatrixAMVPBY(fs->mat[i * no + j], alpha, x + fs->offset[j] * num_col, 1.0, y + fs->offset[i] * num_row);
+}
+
+static void fs_matvec(Matrix* m, value_type* x, value_type* y) { fs_amvpby(m, 1.0, x, 0.0, y); }
+
+static void fs_get_diag(Matrix* m, value_type* diag, index_type bs) {
+    MatrixFS* fs = fs_of(m);
+    index_type no = fs->n_offset, num_row = fs->spy1x1->num_row;
+    UNUSED(bs);
+    HIPGUARD(hipMemsetAsync(diag, 0, sizeof(value_type) * (size_t)fs->offset[no] * (size_t)num_row, DflStream()));
+    for (index_type i = 0; i < no; ++i)
+        if (fs->mat[i * no + i]) MatrixGetDiag(fs->mat[i * no + i], diag + fs->offset[i] * num_row, 1);
+}
+
+static void fs_destroy(Matrix* m) {
+    MatrixFS* fs = fs_of(m);
+    index_type n = fs->n_offset;
+    for (index_type i = 0; i < n * n; ++i)
+        if (fs->mat[i]) MatrixDestroy(fs->mat[i]);
+    CdamFreeDevice(fs->block_val, 0);
+    CdamFreeHost(fs->offset, 0);
+    CdamFreeDevice(fs->d_offset, 0);
+    CdamFreeDevice(fs->d_matval, 0);
+    CdamFreeHost(fs->mat, 0);
+    CdamFreeHost(fs->stream, 0);
+    CdamFreeHost(fs, SIZE_OF(MatrixFS));
+    CdamFreeHost(m, SIZE_OF(Matrix));
+}
+
+Matrix* MatrixCreateTypeFS(index_type n_offset, const index_type* offset, void* ctx) {
+    UNUSED(ctx);
+    Matrix* m = (Matrix*)CdamMallocHost(SIZE_OF(Matrix));
+    memset(m, 0, sizeof *m);
+    m->size[0] = offset[n_offset];
+    m->size[1] = offset[n_offset];
+    m->type = MAT_TYPE_FS;
+    MatrixFS* fs = (MatrixFS*)CdamMallocHost(SIZE_OF(MatrixFS));
+    memset(fs, 0, sizeof *fs);
+    fs->n_offset = n_offset;
+    fs->offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (n_offset + 1));
+    memcpy(fs->offset, offset, sizeof(index_type) * (size_t)(n_offset + 1));
+    fs->d_offset = (index_type*)CdamMallocDevice((n_offset + 1) * SIZE_OF(index_type));
+    HIPGUARD(hipMemcpy(fs->d_offset, offset, sizeof(index_type) * (size_t)(n_offset + 1), H2D));
+    fs->d_matval = (value_type**)CdamMallocDevice(SIZE_OF(value_type*) * n_offset * n_offset);
+    fs->mat = (Matrix**)CdamMallocHost(SIZE_OF(Matrix*) * n_offset * n_offset);
+    memset(fs->mat, 0, sizeof(Matrix*) * (size_t)(n_offset * n_offset));
+    fs->stream = (hipStream_t*)CdamMallocHost(SIZE_OF(hipStream_t) * n_offset); /* never used for launches (matrix.c:489) */
+    memset(fs->stream, 0, sizeof(hipStream_t) * (size_t)n_offset);
+    m->data = fs;
+    m->op->setup = fs_setup;
+    m->op->zero = fs_zero;
+    m->op->zero_row = fs_zero_row;
+    m->op->amvpby = fs_amvpby;
+    m->op->matvec = fs_matvec;
+    m->op->get_diag = fs_get_diag;
+    m->op->destroy = fs_destroy;
+    return m;
+}
+
+value_type* MatrixFSBlockValues(Matrix* m) {
+    if (!m || m->type != MAT_TYPE_FS) return NULL;
+    MatrixFS* fs = fs_of(m);
+    return fs->block_mode ? fs->block_val : NULL;
+}
+
+void MatrixFSExportSubmatrices(Matrix* m) {
+    MatrixFS* fs = fs_of(m);
+    if (!fs->block_mode) return;
+    index_type n = fs->n_offset;
+    dfl_block_export_fs(fs->spy1x1->num_row, fs->spy1x1->row_ptr, fs->block_val, csr_values(fs->mat[0]), csr_values(fs->mat[1]),
+                        csr_values(fs->mat[n]), csr_values(fs->mat[n + 1]), DflStream());
+}
+
+void MatrixFSImportSubmatrices(Matrix* m) {
+    MatrixFS* fs = fs_of(m);
+    if (!fs->block_mode) return;
+    index_type n = fs->n_offset;
+    dfl_block_import_fs(fs->spy1x1->num_row, fs->spy1x1->row_ptr, fs->block_val, csr_values(fs->mat[0]), csr_values(fs->mat[1]),
+                        csr_values(fs->mat[n]), csr_values(fs->mat[n + 1]), DflStream());
+}
+
+/* =============================== dispatch (matrix.c:730-864) ============================ */
+void MatrixDestroy(Matrix* mat) { if (mat) MATRIX_CALL(mat, destroy); }
+void MatrixSetup(Matrix* mat) { ASSERT(mat && "Matrix is NULL"); MATRIX_CALL(mat, setup); }
+void MatrixZero(Matrix* mat) { ASSERT(mat && "Matrix is NULL"); MATRIX_CALL(mat, zero); }
+void MatrixZeroRow(Matrix* mat, index_type n, const index_type* row, index_type shift, value_type diag) {
+    ASSERT(mat && "Matrix is NULL");
+    MATRIX_CALL(mat, zero_row, n, row, shift, diag);
+}
+void MatrixAMVPBY(Matrix* A, value_type alpha, value_type* x, value_type beta, value_type* y) {
+    ASSERT(A && x && y);
+    MATRIX_CALL(A, amvpby, alpha, x, beta, y);
+}
+void MatrixAMVPBYWithMask(Matrix* A, value_type alpha, value_type* x, value_type beta, value_type* y, value_type* lm,
+                          value_type* rm) {
+    ASSERT(A && x && y);
+    MATRIX_CALL(A, amvpby_mask, alpha, x, beta, y, lm, rm);
+}
+void MatrixMatVec(Matrix* mat, value_type* x, value_type* y) { ASSERT(mat && x && y); MATRIX_CALL(mat, matvec, x, y); }
+void MatrixMatVecWithMask(Matrix* mat, value_type* x, value_type* y, value_type* lm, value_type* rm) {
+    ASSERT(mat && x && y);
+    MATRIX_CALL(mat, matvec_mask, x, y, lm, rm);
+}
+void MatrixGetDiag(Matrix* mat, value_type* diag, index_type bs) { ASSERT(mat && diag); MATRIX_CALL(mat, get_diag, diag, bs); }
+void MatrixAddElemValueBlockedBatched(Matrix* mat, index_type nshl, index_type nb, const index_type* batch_ptr,
+                                      const index_type* ien, index_type br, index_type bc, const value_type* val, int lda,
+                                      int stride, const index_type* mask) {
+    ASSERT(mat && "Matrix is NULL");
+    if (mat->op->add_elem_value_blocked_batched)
+        mat->op->add_elem_value_blocked_batched(mat, nshl, nb, batch_ptr, ien, br, bc, val, lda, stride, mask);
+}

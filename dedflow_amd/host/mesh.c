@@ -1,0 +1,244 @@
+/* Mesh containers, coloring/batching and the nodal sparsity pattern.
+ * API of src/MeshData.c, src/Mesh.c, src/color.c, src/csr.c; the algorithms run on
+ * the device through include/dedflow_kernels.h (the reference builds the pattern on
+ * one host thread, src/csr.c:81-190). */
+#include <string.h>
+#include "dedflow.h"
+#include "dedflow_kernels.h"
+#include "host_private.h"
+
+static Mesh3DData* data_create(b32 is_host, index_type nn, index_type nt, index_type np, index_type nh) {
+    Mesh3DData* d = (Mesh3DData*)CdamMallocHost(SIZE_OF(Mesh3DData));
+    ptrdiff_t elem = (ptrdiff_t)nt * 4 + (ptrdiff_t)np * 6 + (ptrdiff_t)nh * 8;
+    ASSERT(nn >= 4 && "Invalid number of nodes");
+    ASSERT(nt + np + nh && "Invalid number of elements");
+    memset(d, 0, sizeof *d);
+    d->is_host = is_host;
+    d->num_node = nn; d->num_tet = nt; d->num_prism = np; d->num_hex = nh;
+    if (is_host) {
+        d->xg = (f64*)CdamMallocHost((ptrdiff_t)nn * 3 * SIZE_OF(f64));
+        d->ien = (index_type*)CdamMallocHost(elem * SIZE_OF(index_type));
+        memset(d->xg, 0, (size_t)nn * 3 * sizeof(f64));
+        memset(d->ien, 0, (size_t)elem * sizeof(index_type));
+    } else {
+        d->xg = (f64*)CdamMallocDevice((ptrdiff_t)nn * 3 * SIZE_OF(f64));
+        d->ien = (index_type*)CdamMallocDevice(elem * SIZE_OF(index_type));
+    }
+    return d;
+}
+Mesh3DData* Mesh3DDataCreateHost(index_type nn, index_type nt, index_type np, index_type nh) { return data_create(TRUE, nn, nt, np, nh); }
+Mesh3DData* Mesh3DDataCreateDevice(index_type nn, index_type nt, index_type np, index_type nh) { return data_create(FALSE, nn, nt, np, nh); }
+
+void Mesh3DDataDestroy(Mesh3DData* d) {
+    if (!d) return;
+    if (d->is_host) { CdamFreeHost(d->xg, 0); CdamFreeHost(d->ien, 0); }
+    else { CdamFreeDevice(d->xg, 0); CdamFreeDevice(d->ien, 0); }
+    CdamFreeHost(d, SIZE_OF(Mesh3DData));
+}
+
+void Mesh3DDataCopy(Mesh3DData* dst, Mesh3DData* src, MemCopyKind kind) {
+    ASSERT(dst && src && "Invalid data");
+    if (src == dst) return;
+    ASSERT(dst->num_node == src->num_node && dst->num_tet == src->num_tet && dst->num_prism == src->num_prism &&
+           dst->num_hex == src->num_hex);
+    size_t elem = (size_t)src->num_tet * 4 + (size_t)src->num_prism * 6 + (size_t)src->num_hex * 8;
+    HIPGUARD(hipMemcpy(dst->xg, src->xg, (size_t)src->num_node * 3 * sizeof(f64), kind));
+    HIPGUARD(hipMemcpy(dst->ien, src->ien, elem * sizeof(index_type), kind));
+}
+
+Mesh3D* Mesh3DCreate(index_type nn, index_type nt, index_type np, index_type nh) {
+    Mesh3D* m = (Mesh3D*)CdamMallocHost(SIZE_OF(Mesh3D));
+    memset(m, 0, sizeof *m);
+    m->num_node = nn; m->num_tet = nt; m->num_prism = np; m->num_hex = nh;
+    m->host = Mesh3DDataCreateHost(nn, nt, np, nh);
+    m->device = Mesh3DDataCreateDevice(nn, nt, np, nh);
+    MeshExt* x = (MeshExt*)CdamMallocHost(SIZE_OF(MeshExt));
+    memset(x, 0, sizeof *x);
+    x->face_group = -1;
+    m->ext = x;
+    return m;
+}
+
+void Mesh3DSetBound(Mesh3D* m, index_type nb, const index_type* node_offset, const index_type* node,
+                    const index_type* elem_offset, const index_type* f2e, const index_type* forn) {
+    m->num_bound = nb;
+    m->bound_node_offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (nb + 1) * 2);
+    m->bound_elem_offset = m->bound_node_offset + nb + 1;
+    memcpy(m->bound_node_offset, node_offset, sizeof(index_type) * (size_t)(nb + 1));
+    memcpy(m->bound_elem_offset, elem_offset, sizeof(index_type) * (size_t)(nb + 1));
+    index_type nbn = node_offset[nb], nf = elem_offset[nb];
+    m->bound_node = (index_type*)CdamMallocDevice(SIZE_OF(index_type) * ((ptrdiff_t)nbn + (ptrdiff_t)nf * 2));
+    m->bound_f2e = m->bound_node + nbn;
+    m->bound_forn = m->bound_f2e + nf;
+    HIPGUARD(hipMemcpy(m->bound_node, node, sizeof(index_type) * (size_t)nbn, H2D));
+    HIPGUARD(hipMemcpy(m->bound_f2e, f2e, sizeof(index_type) * (size_t)nf, H2D));
+    HIPGUARD(hipMemcpy(m->bound_forn, forn, sizeof(index_type) * (size_t)nf, H2D));
+    MeshExt* x = (MeshExt*)m->ext;
+    x->h_f2e = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (ptrdiff_t)(nf > 0 ? nf : 1));
+    memcpy(x->h_f2e, f2e, sizeof(index_type) * (size_t)nf);
+}
+
+void Mesh3DDestroy(Mesh3D* m) {
+    if (!m) return;
+    MeshExt* x = (MeshExt*)m->ext;
+    Mesh3DDataDestroy(m->host);
+    Mesh3DDataDestroy(m->device);
+    if (m->bound_node_offset) CdamFreeHost(m->bound_node_offset, 0);
+    CdamFreeDevice(m->bound_node, 0);
+    if (m->batch_offset) CdamFreeHost(m->batch_offset, 0);
+    CdamFreeDevice(m->batch_ind, 0);
+    CdamFreeDevice(m->color, 0);
+    if (x) {
+        CdamFreeDevice(x->ien_b, 0);
+        CdamFreeDevice(x->nzmap_b, 0);
+        CdamFreeDevice(x->face_list, 0);
+        if (x->face_color_offset) CdamFreeHost(x->face_color_offset, 0);
+        if (x->h_f2e) CdamFreeHost(x->h_f2e, 0);
+        CdamFreeHost(x, SIZE_OF(MeshExt));
+    }
+    CdamFreeHost(m, SIZE_OF(Mesh3D));
+}
+
+void Mesh3DUpdateHost(Mesh3D* m) { Mesh3DDataCopy(m->host, m->device, D2H); }
+void Mesh3DUpdateDevice(Mesh3D* m) { Mesh3DDataCopy(m->device, m->host, H2D); }
+
+/* ColorMeshTet, src/color.c:14-57: V2E map, XORWOW priorities, JPL rounds */
+void ColorMeshTet(const Mesh3D* mesh, index_type max_color_len, color_t* color) {
+    const Mesh3DData* dev = Mesh3DDevice(mesh);
+    const index_type* ien = dev->ien;
+    index_type T = dev->num_tet, N = dev->num_node;
+    UNUSED(max_color_len);
+    index_type* row = (index_type*)CdamMallocDevice(((ptrdiff_t)N + 1) * SIZE_OF(index_type));
+    GenerateV2EMapRowTetGPU(ien, T, N, row);
+    index_type nnz = 0;
+    HIPGUARD(hipMemcpy(&nnz, row + N, sizeof nnz, D2H));
+    index_type* col = (index_type*)CdamMallocDevice((ptrdiff_t)nnz * SIZE_OF(index_type));
+    GenerateV2EMapColTetGPU(ien, T, N, row, col);
+    ColorElementJPLTetGPU(ien, row, col, MAX_COLOR, color, T);
+    CdamFreeDevice(row, 0);
+    CdamFreeDevice(col, 0);
+}
+
+color_t GetMaxColor(const color_t* color, index_type n) {
+    color_t mc = 0;
+    GetMaxColorGPU(color, n, &mc);
+    return mc;
+}
+
+void Mesh3DColor(Mesh3D* mesh) {
+    index_type T = mesh->num_tet;
+    if (!mesh->color) mesh->color = (color_t*)CdamMallocDevice((ptrdiff_t)T * SIZE_OF(color_t));
+    ColorMeshTet(mesh, MAX_COLOR, mesh->color);
+    mesh->num_color = GetMaxColor(mesh->color, T) + 1;
+}
+
+/* Mesh3DGenerateColorBatch, src/Mesh.c:165-206.  The per-color count + copy_if passes
+ * are one stable sort by color; additionally the connectivity is re-laid out in batch
+ * order so that each color's launch streams its ien (and nz map) contiguously. */
+void Mesh3DGenerateColorBatch(Mesh3D* mesh) {
+    index_type T = mesh->num_tet;
+    MeshExt* x = (MeshExt*)mesh->ext;
+    if (!T) return;
+    Mesh3DColor(mesh);
+    index_type nc = mesh->num_color;
+    mesh->num_batch = nc;
+    mesh->batch_offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (nc + 1));
+    mesh->batch_ind = (index_type*)CdamMallocDevice((ptrdiff_t)T * SIZE_OF(index_type));
+    dfl_color_batches(mesh->color, T, nc, mesh->batch_offset, mesh->batch_ind);
+    x->ien_b = (index_type*)CdamMallocDevice((ptrdiff_t)T * 4 * SIZE_OF(index_type));
+    dfl_gather_ien(T, mesh->device->ien, mesh->batch_ind, x->ien_b, DflStream());
+    HIPGUARD(hipStreamSynchronize(DflStream()));
+}
+
+/* faces of one boundary group ordered by the color of their parent tet
+ * (replaces the per-color SetupMaskKernel passes, src/assemble.cu:1916-1945) */
+void DflMeshPrepareFaces(Mesh3D* mesh, index_type group) {
+    MeshExt* x = (MeshExt*)mesh->ext;
+    if (x->face_group == group) return;
+    index_type nf = Mesh3DBoundNumElem(mesh, group), nc = mesh->num_color, T = mesh->num_tet;
+    index_type lo = mesh->bound_elem_offset[group];
+    CdamFreeDevice(x->face_list, 0);
+    if (x->face_color_offset) CdamFreeHost(x->face_color_offset, 0);
+    x->face_color_offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (nc + 1));
+    index_type* h_color = (index_type*)CdamMallocHost((ptrdiff_t)T * SIZE_OF(index_type));
+    HIPGUARD(hipMemcpy(h_color, mesh->color, sizeof(index_type) * (size_t)T, D2H));
+    index_type* list = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (ptrdiff_t)(nf > 0 ? nf : 1));
+    memset(x->face_color_offset, 0, sizeof(index_type) * (size_t)(nc + 1));
+    for (index_type f = 0; f < nf; ++f) x->face_color_offset[h_color[x->h_f2e[lo + f]] + 1]++;
+    for (index_type c = 0; c < nc; ++c) x->face_color_offset[c + 1] += x->face_color_offset[c];
+    index_type* cur = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (nc + 1));
+    memcpy(cur, x->face_color_offset, sizeof(index_type) * (size_t)(nc + 1));
+    for (index_type f = 0; f < nf; ++f) list[cur[h_color[x->h_f2e[lo + f]]]++] = f; /* stable: ascending face id per color */
+    x->face_list = (index_type*)CdamMallocDevice(SIZE_OF(index_type) * (ptrdiff_t)(nf > 0 ? nf : 1));
+    HIPGUARD(hipMemcpy(x->face_list, list, sizeof(index_type) * (size_t)nf, H2D));
+    x->face_group = group;
+    CdamFreeHost(cur, 0);
+    CdamFreeHost(list, 0);
+    CdamFreeHost(h_color, 0);
+}
+
+/* ---- csr.h ------------------------------------------------------------------------ */
+CSRAttr* CSRAttrCreate(const Mesh3D* mesh) {
+    CSRAttr* attr = (CSRAttr*)CdamMallocHost(SIZE_OF(CSRAttr));
+    memset(attr, 0, sizeof *attr);
+    const Mesh3DData* dev = Mesh3DDevice(mesh);
+    index_type N = dev->num_node, T = dev->num_tet;
+    hipStream_t s = DflStream();
+    attr->num_row = N;
+    attr->num_col = N;
+    /* vertex->element map, then sorted unique neighbour lists per node */
+    index_type* vrow = (index_type*)CdamMallocDevice(((ptrdiff_t)N + 1) * SIZE_OF(index_type));
+    GenerateV2EMapRowTetGPU(dev->ien, T, N, vrow);
+    index_type vnnz = 0;
+    HIPGUARD(hipMemcpy(&vnnz, vrow + N, sizeof vnnz, D2H));
+    index_type* vcol = (index_type*)CdamMallocDevice((ptrdiff_t)vnnz * SIZE_OF(index_type));
+    GenerateV2EMapColTetGPU(dev->ien, T, N, vrow, vcol);
+    index_type* len = (index_type*)CdamMallocDevice(((ptrdiff_t)N + 1) * SIZE_OF(index_type));
+    index_type* d_over = (index_type*)CdamMallocDevice(SIZE_OF(index_type));
+    dfl_pattern_count(N, dev->ien, vrow, vcol, len, d_over, s);
+    attr->row_ptr = (index_type*)CdamMallocDevice(((ptrdiff_t)N + 1) * SIZE_OF(index_type));
+    int64_t tb = dfl_scan_temp_bytes(N);
+    void* tmp = CdamMallocDevice((ptrdiff_t)tb);
+    dfl_exclusive_scan_i32(N, len, attr->row_ptr, tmp, tb, s);
+    index_type over = 0, nnz = 0;
+    HIPGUARD(hipMemcpyAsync(&over, d_over, sizeof over, D2H, s));
+    HIPGUARD(hipMemcpyAsync(&nnz, attr->row_ptr + N, sizeof nnz, D2H, s));
+    HIPGUARD(hipStreamSynchronize(s));
+    ASSERT(!over && "CSRHashMapPush: row overflow"); /* csr.c:63 */
+    attr->nnz = nnz;
+    attr->col_ind = (index_type*)CdamMallocDevice((ptrdiff_t)nnz * SIZE_OF(index_type));
+    dfl_pattern_fill(N, dev->ien, vrow, vcol, attr->row_ptr, attr->col_ind, s);
+    HIPGUARD(hipStreamSynchronize(s));
+    CdamFreeDevice(tmp, 0);
+    CdamFreeDevice(len, 0);
+    CdamFreeDevice(d_over, 0);
+    CdamFreeDevice(vrow, 0);
+    CdamFreeDevice(vcol, 0);
+    return attr;
+}
+
+CSRAttr* CSRAttrCreateBlock(const CSRAttr* attr, csr_index_type br, csr_index_type bc) {
+    CSRAttr* na = (CSRAttr*)CdamMallocHost(SIZE_OF(CSRAttr));
+    memset(na, 0, sizeof *na);
+    na->num_row = attr->num_row * br;
+    na->num_col = attr->num_col * bc;
+    na->nnz = attr->nnz * br * bc;
+    na->parent = attr;
+    na->row_ptr = (index_type*)CdamMallocDevice(((ptrdiff_t)na->num_row + 1) * SIZE_OF(index_type));
+    na->col_ind = (index_type*)CdamMallocDevice((ptrdiff_t)na->nnz * SIZE_OF(index_type));
+    if (br == 1 && bc == 1) {
+        HIPGUARD(hipMemcpy(na->row_ptr, attr->row_ptr, sizeof(index_type) * (size_t)(attr->num_row + 1), D2D));
+        HIPGUARD(hipMemcpy(na->col_ind, attr->col_ind, sizeof(index_type) * (size_t)attr->nnz, D2D));
+    } else {
+        dfl_csr_expand(attr->num_row, attr->row_ptr, attr->col_ind, br, bc, na->row_ptr, na->col_ind, DflStream());
+        HIPGUARD(hipStreamSynchronize(DflStream()));
+    }
+    return na;
+}
+
+void CSRAttrDestroy(CSRAttr* attr) {
+    if (!attr) return;
+    CdamFreeDevice(attr->row_ptr, 0);
+    CdamFreeDevice(attr->col_ind, 0);
+    CdamFreeHost(attr, SIZE_OF(CSRAttr));
+}

@@ -1,0 +1,400 @@
+/* dedflow.h -- host-side object API of the MI355X implementation of DEDFlow's
+ * per-timestep hot path.  One consolidated header that keeps the names,
+ * argument meaning and struct prefixes of the reference's public headers so a
+ * caller written against them (src/main.c) compiles against this library:
+ *
+ *   common.h:20-111   scalar typedefs, ASSERT/CEIL_DIV, Init/Finalize, GlobalContextGet
+ *   alloc.h:19-36     Allocator vtable, CdamMalloc{Host,Device}/CdamFree{Host,Device}
+ *   MeshData.h:10-36  Mesh3DData           Mesh.h:14-73   Mesh3D
+ *   csr.h:14-36       CSRAttr              matrix.h:27-147 Matrix / MatrixOp / MatrixCSR / MatrixFS
+ *   vec.h:7-10        Vec*                 dirichlet.h:8-33 Dirichlet
+ *   pc.h:15-88        PC tree              krylov.h:12-30  Krylov
+ *   assemble.h:13-14  AssembleSystemTet / AssembleSystemTetFace
+ *   Array.h:11-39 / Particle.h:13-35       Array, ParticleContext
+ *
+ * Differences a caller can observe (all listed in INTEGRATION.md):
+ *   - cudaStream_t fields are hipStream_t.
+ *   - A MatrixFS holding the reference's (u,p) 2x2 layout stores ONE shared-pattern
+ *     array of 4x4 blocks (include/dedflow_kernels.h); sub-matrix `val` arrays in the
+ *     reference layout are materialised only by MatrixFSExportSubmatrices().
+ *   - structs end with one extra `ext` pointer owned by the library.
+ *   - expanded patterns have a correct last row_ptr entry (reference bug Q3).
+ * No status returns, guard-and-trap error behaviour, caller-owned buffers, one
+ * host thread: as in the reference.
+ */
+#ifndef DEDFLOW_H
+#define DEDFLOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scalars (common.h:20-66) ------------------------------------------------- */
+typedef int8_t i8;
+typedef int16_t i16;
+typedef int32_t i32;
+typedef int64_t i64;
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef float f32;
+typedef double f64;
+typedef char byte;
+typedef f64 value_type;  /* -DUSE_F64_VALUE */
+typedef i32 index_type;  /* -DUSE_I32_INDEX */
+typedef int32_t b32;
+typedef i32 color_t;
+#ifndef TRUE
+#define TRUE (1 == 1)
+#define FALSE (1 == 0)
+#endif
+#define SIZE_OF(x) ((index_type)sizeof(x))
+#define CEIL_DIV(a, b) (((a) + (b)-1) / (b))
+#define UNUSED(args) ((void)(args))
+#if defined(NDEBUG)
+#define ASSERT(expr) /* empty */
+#else
+#define ASSERT(expr) \
+    while (!(expr)) __builtin_trap()
+#endif
+typedef hipMemcpyKind MemCopyKind;
+#define H2D (hipMemcpyHostToDevice)
+#define D2H (hipMemcpyDeviceToHost)
+#define D2D (hipMemcpyDeviceToDevice)
+#define H2H (hipMemcpyHostToHost)
+void DflGuardPrivate(hipError_t code, const char* file, int line);
+#define HIPGUARD(err) DflGuardPrivate((err), __FILE__, __LINE__)
+
+#define UNCOLORED (0x0)
+#define MAX_COLOR (1 << 8)
+
+/* ---- runtime (common.h:103-111, alloc.h) --------------------------------------- */
+void Init(int argc, char** argv);
+void Finalize(void);
+typedef enum GlobalContextType { GLOBAL_CONTEXT_SPARSE_HANDLE = 0, GLOBAL_CONTEXT_BLAS_HANDLE = 1 } GlobalContextType;
+/* the reference returns cuSPARSE/cuBLAS handles here; this library has no vendor
+ * handles -- both slots return a pointer to the hipStream_t every launcher uses. */
+void* GlobalContextGet(GlobalContextType type);
+hipStream_t DflStream(void);
+void DflSetStream(hipStream_t s);
+
+typedef enum DeviceType { HOST = 0, DEVICE = 1 } DeviceType;
+typedef void* UserCtxPtr;
+typedef struct Allocator {
+    void* (*malloc)(ptrdiff_t, UserCtxPtr);
+    void (*free)(void*, ptrdiff_t, UserCtxPtr);
+    UserCtxPtr ctx;
+} Allocator;
+Allocator* GetDefaultAllocator(int device_id);
+#define CdamMallocHost(count) (GetDefaultAllocator(HOST)->malloc((ptrdiff_t)(count), GetDefaultAllocator(HOST)->ctx))
+#define CdamFreeHost(ptr, count) (GetDefaultAllocator(HOST)->free(ptr, (ptrdiff_t)(count), GetDefaultAllocator(HOST)->ctx))
+#define CdamMallocDevice(count) (GetDefaultAllocator(DEVICE)->malloc((ptrdiff_t)(count), GetDefaultAllocator(DEVICE)->ctx))
+#define CdamFreeDevice(ptr, count) (GetDefaultAllocator(DEVICE)->free(ptr, (ptrdiff_t)(count), GetDefaultAllocator(DEVICE)->ctx))
+
+/* ---- mesh (MeshData.h, Mesh.h) --------------------------------------------------- */
+typedef struct H5FileInfo H5FileInfo;
+typedef struct Mesh3DData {
+    b32 is_host;
+    index_type num_node, num_tet, num_prism, num_hex;
+    f64* xg;         /* xg[3*num_node] */
+    index_type* ien; /* ien[4*num_tet + 6*num_prism + 8*num_hex] */
+} Mesh3DData;
+#define Mesh3DDataNumNode(data) ((data)->num_node)
+#define Mesh3DDataNumTet(data) ((data)->num_tet)
+#define Mesh3DDataNumPrism(data) ((data)->num_prism)
+#define Mesh3DDataNumHex(data) ((data)->num_hex)
+#define Mesh3DDataCoord(data) ((data)->xg)
+#define Mesh3DDataIEN(data) ((data)->ien)
+#define Mesh3DDataTet(data) (Mesh3DDataNumTet(data) ? (data)->ien + 0 : NULL)
+Mesh3DData* Mesh3DDataCreateHost(index_type num_node, index_type num_tet, index_type num_prism, index_type num_hex);
+Mesh3DData* Mesh3DDataCreateDevice(index_type num_node, index_type num_tet, index_type num_prism, index_type num_hex);
+void Mesh3DDataDestroy(Mesh3DData* data);
+void Mesh3DDataCopy(Mesh3DData* dst, Mesh3DData* src, MemCopyKind kind);
+
+typedef struct Mesh3D {
+    index_type num_node, num_tet, num_prism, num_hex;
+    Mesh3DData* host;
+    Mesh3DData* device;
+    index_type num_bound;
+    index_type* bound_fid;
+    index_type* bound_node_offset; /* host */
+    index_type* bound_node;        /* device */
+    index_type* bound_elem_offset; /* host */
+    index_type* bound_ien;
+    index_type* bound_f2e;  /* device */
+    index_type* bound_forn; /* device */
+    index_type num_batch;
+    index_type* batch_offset; /* host */
+    index_type* batch_ind;    /* device */
+    color_t num_color;
+    color_t* color; /* device */
+    void* ext;      /* library-owned: batch-ordered ien, (elem,a,b)->nz map, face lists */
+} Mesh3D;
+#define Mesh3DHost(mesh) ((mesh)->host)
+#define Mesh3DDevice(mesh) ((mesh)->device)
+#define Mesh3DNumNode(mesh) ((mesh)->num_node)
+#define Mesh3DNumTet(mesh) ((mesh)->num_tet)
+#define Mesh3DNumPrism(mesh) ((mesh)->num_prism)
+#define Mesh3DNumHex(mesh) ((mesh)->num_hex)
+#define Mesh3DBoundNumNode(mesh, i) ((mesh)->bound_node_offset[(i) + 1] - (mesh)->bound_node_offset[(i)])
+#define Mesh3DBoundNode(mesh, i) ((mesh)->bound_node + (mesh)->bound_node_offset[(i)])
+#define Mesh3DBoundNumElem(mesh, i) ((mesh)->bound_elem_offset[(i) + 1] - (mesh)->bound_elem_offset[(i)])
+#define Mesh3DBoundF2E(mesh, i) ((mesh)->bound_f2e + (mesh)->bound_elem_offset[(i)])
+#define Mesh3DBoundFORN(mesh, i) ((mesh)->bound_forn + (mesh)->bound_elem_offset[(i)])
+Mesh3D* Mesh3DCreate(index_type num_node, index_type num_tet, index_type num_prism, index_type num_hex);
+Mesh3D* Mesh3DCreateH5(H5FileInfo* h5f, const char* group_name);
+void Mesh3DDestroy(Mesh3D* mesh);
+void Mesh3DUpdateHost(Mesh3D* mesh);
+void Mesh3DUpdateDevice(Mesh3D* mesh);
+void Mesh3DColor(Mesh3D* mesh);
+void Mesh3DGenerateColorBatch(Mesh3D* mesh);
+/* boundary groups from host arrays (the reference only fills them from HDF5, Mesh.c:12-59) */
+void Mesh3DSetBound(Mesh3D* mesh, index_type num_bound, const index_type* node_offset, const index_type* node,
+                    const index_type* elem_offset, const index_type* f2e, const index_type* forn);
+void ColorMeshTet(const Mesh3D* mesh, index_type max_color_len, color_t* color);
+color_t GetMaxColor(const color_t* color, index_type num_elem);
+
+/* ---- sparsity (csr.h) ------------------------------------------------------------ */
+typedef index_type csr_index_type;
+typedef struct CSRAttr CSRAttr;
+struct CSRAttr {
+    index_type num_row, num_col, nnz;
+    index_type* row_ptr; /* device */
+    index_type* col_ind; /* device */
+    const CSRAttr* parent;
+};
+#define CSRAttrNumRow(attr) ((attr)->num_row)
+#define CSRAttrNumCol(attr) ((attr)->num_col)
+#define CSRAttrNNZ(attr) ((attr)->nnz)
+#define CSRAttrRowPtr(attr) ((attr)->row_ptr)
+#define CSRAttrColInd(attr) ((attr)->col_ind)
+CSRAttr* CSRAttrCreate(const Mesh3D* mesh);
+void CSRAttrDestroy(CSRAttr* attr);
+CSRAttr* CSRAttrCreateBlock(const CSRAttr* attr, csr_index_type block_row, csr_index_type block_col);
+
+/* ---- matrices (matrix.h) --------------------------------------------------------- */
+typedef enum MatType { MAT_TYPE_NONE = 0, MAT_TYPE_DENSE = 1, MAT_TYPE_CSR = 2, MAT_TYPE_FS = 4, MAT_TYPE_CUSTOM = 8 } MatType;
+typedef struct Matrix Matrix;
+typedef struct MatrixOp {
+    void (*setup)(Matrix* matrix);
+    void (*zero)(Matrix* matrix);
+    void (*zero_row)(Matrix* matrix, index_type, const index_type* row, index_type shift, value_type diag);
+    void (*amvpby)(Matrix* A, value_type alpha, value_type* x, value_type beta, value_type* y);
+    void (*amvpby_mask)(Matrix* A, value_type alpha, value_type* x, value_type beta, value_type* y, value_type* left_mask,
+                        value_type* right_mask);
+    void (*matvec)(Matrix* matrix, value_type* x, value_type* y);
+    void (*matvec_mask)(Matrix* matrix, value_type* x, value_type* y, value_type* left_mask, value_type* right_mask);
+    void (*get_diag)(Matrix* matrix, value_type* diag, index_type bs);
+    void (*set_values_coo)(Matrix* matrix, value_type alpha, index_type n, const index_type* row, const index_type* col,
+                           const value_type* val, value_type beta);
+    void (*set_values_ind)(Matrix* matrix, value_type alpha, index_type n, const index_type* ind, const value_type* val,
+                           value_type beta);
+    void (*add_elem_value_batched)(Matrix* matrix, index_type nshl, index_type batch_size, const index_type* batch_ptr,
+                                   const index_type* ien, const value_type* val, const index_type* mask);
+    void (*add_elem_value_blocked_batched)(Matrix* matrix, index_type nshl, index_type batch_size, const index_type* batch_ptr,
+                                           const index_type* ien, index_type block_row_size, index_type block_col_size,
+                                           const value_type* val, int lda, int stride, const index_type* mask);
+    void (*add_value_batched)(Matrix* matrix, index_type batch_size, const index_type* batch_row_ind,
+                              const index_type* batch_col_ind, const value_type* A);
+    void (*add_value_blocked_batched)(Matrix* matrix, index_type batch_size, const index_type* batch_row_ind,
+                                      const index_type* batch_col_ind, index_type block_row, index_type block_col,
+                                      const value_type* A, int lda, int stride);
+    void (*destroy)(Matrix* matrix);
+} MatrixOp;
+struct Matrix {
+    index_type size[2];
+    MatType type;
+    void* data;
+    hipStream_t stream_ref;
+    MatrixOp op[1];
+};
+#define MatrixNumRow(A) ((A)->size[0])
+#define MatrixNumCol(A) ((A)->size[1])
+#define MatrixType(A) ((A)->type)
+typedef struct MatrixFS MatrixFS;
+typedef struct MatrixCSR {
+    b32 external_attr;
+    const CSRAttr* attr;
+    value_type* val; /* reference-layout values; NULL while the matrix is a view into a block-mode MatrixFS */
+    void* descr;     /* unused (cusparseSpMatDescr_t in the reference) */
+    index_type buffer_size;
+    void* buffer;
+    /* ext */
+    MatrixFS* owner;       /* block-mode parent, or NULL */
+    index_type owner_slot; /* i * n_offset + j inside the parent */
+} MatrixCSR;
+struct MatrixFS {
+    index_type n_offset;
+    index_type* offset;
+    index_type* d_offset;
+    hipStream_t* stream;
+    const CSRAttr* spy1x1;
+    value_type** d_matval;
+    Matrix** mat;
+    /* ext */
+    b32 block_mode;        /* the (u,p) 2x2 layout of src/main.c:374-391 was recognised */
+    value_type* block_val; /* [nnz1][16] device, 4x4 blocks over spy1x1 */
+};
+Matrix* MatrixCreateTypeCSR(const CSRAttr* attr, void*);
+Matrix* MatrixCreateTypeFS(index_type n_offset, const index_type* offset, void*);
+void MatrixDestroy(Matrix* matrix);
+void MatrixSetup(Matrix* matrix);
+void MatrixZero(Matrix* matrix);
+void MatrixZeroRow(Matrix* matrix, index_type n, const index_type* row, index_type shift, value_type diag);
+void MatrixAMVPBY(Matrix* A, value_type alpha, value_type* x, value_type beta, value_type* y);
+void MatrixAMVPBYWithMask(Matrix* A, value_type alpha, value_type* x, value_type beta, value_type* y, value_type* left_mask,
+                          value_type* right_mask);
+void MatrixMatVec(Matrix* matrix, value_type* x, value_type* y);
+void MatrixMatVecWithMask(Matrix* matrix, value_type* x, value_type* y, value_type* left_mask, value_type* right_mask);
+void MatrixGetDiag(Matrix* matrix, value_type* diag, index_type bs);
+void MatrixAddElemValueBlockedBatched(Matrix* matrix, index_type nshl, index_type num_batch, const index_type* batch_ptr,
+                                      const index_type* ien, index_type block_row_size, index_type block_col_size,
+                                      const value_type* val, int lda, int stride, const index_type* mask);
+/* block-mode helpers (not in the reference) */
+value_type* MatrixFSBlockValues(Matrix* matrix); /* NULL unless block mode */
+/* fills the four sub-matrices' `val` arrays (reference layout) from the block storage, allocating them on first use */
+void MatrixFSExportSubmatrices(Matrix* matrix);
+void MatrixFSImportSubmatrices(Matrix* matrix);
+
+/* ---- vectors (vec.h) --------------------------------------------------------------- */
+void VecAXPY(value_type a, const value_type* x, value_type* y, index_type n);
+void VecPointwiseMult(const value_type* x, const value_type* y, value_type* z, index_type n);
+void VecPointwiseDiv(const value_type* x, const value_type* y, value_type* z, index_type n);
+void VecPointwiseInv(value_type* x, index_type n);
+
+/* ---- Dirichlet (dirichlet.h) --------------------------------------------------------- */
+typedef enum BCType { BC_NONE = 0, BC_STRONG = 1, BC_WEAK = 2, BC_OUTFLOW = 4 } BCType;
+typedef struct Dirichlet {
+    const Mesh3D* mesh;
+    index_type face_ind;
+    index_type shape;
+    size_t buffer_size;
+    void* buffer;
+    BCType bctype[];
+} Dirichlet;
+Dirichlet* DirichletCreate(const Mesh3D* mesh, index_type face_ind, index_type shape);
+void DirichletDestroy(Dirichlet* dirichlet);
+void DirichletApplyVec(Dirichlet* dirichlet, value_type* b);
+void DirichletApplyMat(Dirichlet* dirichlet, Matrix* A);
+
+/* ---- preconditioners (pc.h) ---------------------------------------------------------- */
+typedef enum PCType { PC_NONE = 0x0, PC_JACOBI = 0x1, PC_DECOMPOSITION = 0x2, PC_AMGX = 0x3, PC_CUSTOM = 0x4, PC_ILU0 = 0x5 } PCType;
+typedef struct PC PC;
+typedef struct PCOps {
+    void (*setup)(PC*);
+    void (*destroy)(PC*);
+    void (*apply)(PC*, value_type*, value_type*);
+} PCOps;
+struct PC {
+    PCType type;
+    void* mat;
+    PCOps op[1];
+    void* data;
+    void* cublas_handle; /* kept for layout compatibility; unused */
+};
+typedef struct PCNone { index_type n; } PCNone;
+typedef struct PCJacobi { index_type n; index_type bs; void* diag; } PCJacobi;
+typedef struct PCDecomposition { index_type n_sec; index_type* offset; PC** pc; void* ext; } PCDecomposition;
+PC* PCCreateNone(Matrix* mat, index_type n);
+PC* PCCreateJacobi(Matrix* mat, index_type bs, void* handle);
+PC* PCCreateDecomposition(Matrix* mat, index_type n, const index_type* offset, void* handle);
+PC* PCCreateAMGX(Matrix* mat, void* options); /* returns NULL: NVIDIA-only external library (pc.c:300-304) */
+void PCSetup(PC* pc);
+void PCDestroy(PC* pc);
+void PCApply(PC* pc, f64* x, f64* y);
+
+/* ---- Krylov (krylov.h) ---------------------------------------------------------------- */
+typedef void (*KSPSolveFunc)(Matrix*, value_type*, value_type*, void*);
+typedef struct Krylov {
+    index_type max_iter;
+    f64 atol, rtol;
+    void* handle;
+    KSPSolveFunc ksp_solve;
+    size_t ksp_ctx_size;
+    void* ksp_ctx;
+    void* pc;
+    void* ext; /* library-owned workspace + statistics (KrylovStats) */
+} Krylov;
+Krylov* KrylovCreateCG(index_type, f64, f64, void*);    /* stub in the reference (krylov.c:42-51); build-defined here */
+Krylov* KrylovCreateGMRES(index_type, f64, f64, void*);
+void KrylovDestroy(Krylov* krylov);
+/* argument order of the DEFINITION and the call site (krylov.c:386, main.c:217): (ksp, A, x, b) -- Q10 */
+void KrylovSolve(Krylov* krylov, Matrix* A, f64* x, f64* b);
+typedef struct KrylovStats {
+    index_type iterations;
+    f64 rnrm_init;
+    f64 res_hist[512]; /* |beta[k+1]| after iteration k */
+    b32 converged;
+} KrylovStats;
+const KrylovStats* KrylovGetStats(const Krylov* krylov);
+/* 0: GMRES tests convergence every 20 iterations like the reference (krylov.c:281-290); k>0: every k */
+void KrylovSetCheckInterval(Krylov* krylov, index_type k);
+void KrylovSetVerbose(Krylov* krylov, b32 verbose);
+/* optional communicator for element-partitioned runs (one process per GPU); NULL = single GPU */
+typedef struct DflComm {
+    void (*allreduce_sum)(void* ctx, f64* d_buf, index_type n); /* in place, device buffer */
+    void (*halo_exchange)(void* ctx, f64* d_x);                /* fill ghost entries of a [u|p|..] vector */
+    void* ctx;
+    index_type num_owned_node; /* dots / norms run over owned nodes only */
+} DflComm;
+void KrylovSetComm(Krylov* krylov, const DflComm* comm);
+
+/* ---- assembly (assemble.h) ------------------------------------------------------------ */
+void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J);
+void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J);
+/* the caller of the hot path, src/main.c:31-75 (static there) */
+void AssembleSystem(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, Dirichlet** bcs, index_type nbc);
+void DflSetQuiet(b32 quiet); /* suppress the reference's stdout chatter ("Assemble: F J", timers) */
+
+/* ---- arrays / particles (Array.h, Particle.h) ------------------------------------------ */
+typedef struct Array {
+    b32 is_host;
+    index_type len;
+    f64* data;
+} Array;
+#define ArrayLen(a) ((a)->len)
+#define ArrayData(a) ((a)->data)
+Array* ArrayCreateHost(index_type len);
+Array* ArrayCreateDevice(index_type len);
+void ArrayDestroy(Array* a);
+void ArrayCopy(Array* dst, const Array* src, MemCopyKind kind);
+typedef struct ParticleContext {
+    index_type num_particle;
+    i32 num_pointwise_dof;
+    Array* h_arr[3];
+    Array* d_arr[3];
+    f64 buff[2];
+    void* ext; /* cell list workspace of the DEM sweep */
+} ParticleContext;
+#define ParticleCTXNumParticle(pctx) ((pctx)->num_particle)
+#define ParticleCTXHostCoord(pctx) ((pctx)->h_arr[0])
+#define ParticleCTXHostVel(pctx) ((pctx)->h_arr[1])
+#define ParticleCTXHostAcc(pctx) ((pctx)->h_arr[2])
+#define ParticleCTXDeviceCoord(pctx) ((pctx)->d_arr[0])
+#define ParticleCTXDeviceVel(pctx) ((pctx)->d_arr[1])
+#define ParticleCTXDeviceAcc(pctx) ((pctx)->d_arr[2])
+#define ParticleMass(pctx) (((pctx)->buff)[0])
+#define ParticleRadius(pctx) (((pctx)->buff)[1])
+ParticleContext* ParticleContextCreate(index_type num_particle);
+void ParticleContextDestroy(ParticleContext* ctx);
+void ParticleContextCopy(ParticleContext* dst, const ParticleContext* src);
+void ParticleContextUpdateHost(ParticleContext* ctx);
+void ParticleContextUpdateDevice(ParticleContext* ctx);
+void ParticleContextAdd(ParticleContext* ctx);
+/* empty in the reference (Particle.c:120-130); here: contact-force sweep + explicit update (build-defined) */
+void ParticleContextUpdate(ParticleContext* ctx);
+void ParticleContextRemove(ParticleContext* ctx);
+void ParticleContextSetContactModel(ParticleContext* ctx, f64 kn, f64 gamma_n, f64 dt);
+void ParticleContextComputeForces(ParticleContext* ctx); /* acc <- contact forces / mass */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEDFLOW_H */

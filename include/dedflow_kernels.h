@@ -1,0 +1,194 @@
+/* dedflow_kernels.h -- thin C ABI of the hand-written gfx950 (MI355X) kernels.
+ *
+ * Plain pointers and sizes only (no torch / C++ types).  Every pointer is a
+ * DEVICE pointer unless the name starts with h_.  `stream` is a hipStream_t
+ * passed as void* (NULL = the null stream).  Launchers are asynchronous and
+ * never allocate, free or synchronise unless their comment says so; the caller
+ * owns every buffer (same ownership rule as the reference).
+ *
+ * Each entry cites the reference interface it replaces (paths relative to
+ * zexxzhao/DEDFlow @ 2024-10-16).  Where the reference called a vendor library
+ * from host C (cuBLAS / cuSPARSE / cuRAND / Thrust / CUB) the replacement is a
+ * dfl_* launcher here.
+ *
+ * Native matrix layout ("block CSR"): one nodal pattern (row_ptr[N+1],
+ * col_ind[nnz1], sorted ascending per row) shared by all sub-matrices and one
+ * 4x4 block of f64 per nodal nonzero, val[k*16 + r*4 + c] with r,c in
+ * (u0,u1,u2,p).  It replaces the reference's four row-expanded scalar CSR
+ * arrays A00/A01/A10/A11 (src/main.c:385-391, src/csr_impl.cu:24-59); the
+ * phi/T rows and columns are not stored, exactly as the reference drops them
+ * (NULL sub-matrices, src/matrix_impl.cu:424-426).  dfl_block_export_fs /
+ * dfl_block_import_fs convert to/from the reference layout.
+ * Global vectors keep the reference layout [u: Nx3 AoS | p: N | phi: N | T: N]
+ * (src/main.c:108-118).
+ */
+#ifndef DEDFLOW_KERNELS_H
+#define DEDFLOW_KERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t dfl_index;   /* index_type  = i32 (config/config.mk:51) */
+typedef double dfl_value;    /* value_type  = f64 */
+
+/* ---- library / device ------------------------------------------------------- */
+int dfl_abi_version(void);
+/* last HIP error text seen by a launcher (thread-unsafe, like the reference's CUGUARD printf) */
+const char* dfl_last_error(void);
+
+/* ---- BLAS-1 on device vectors (replaces cublasD{axpy,copy,scal,nrm2,dot},
+ *      src/krylov.c:114-319, src/main.c:107-130,226,242-265,544-565; VecAXPY etc. src/vec.cu:14-76) */
+void dfl_daxpy(dfl_index n, dfl_value alpha, const dfl_value* x, dfl_value* y, void* stream);
+void dfl_dscal(dfl_index n, dfl_value alpha, dfl_value* x, void* stream);
+void dfl_dcopy(dfl_index n, const dfl_value* x, dfl_value* y, void* stream);
+void dfl_dset(dfl_index n, dfl_value alpha, dfl_value* x, void* stream);               /* SetValGPU, matrix_impl.cu:467-471 */
+void dfl_pointwise_mult(dfl_index n, const dfl_value* x, const dfl_value* y, dfl_value* z, void* stream); /* VecPointwiseMult */
+void dfl_pointwise_div(dfl_index n, const dfl_value* x, const dfl_value* y, dfl_value* z, void* stream);  /* VecPointwiseDiv  */
+void dfl_pointwise_inv(dfl_index n, dfl_value* x, void* stream);                                          /* VecPointwiseInv  */
+/* deterministic two-stage reductions; result written to *d_out (device).  `work`
+ * holds at least dfl_reduce_work_size() doubles. */
+dfl_index dfl_reduce_work_size(void);
+void dfl_ddot(dfl_index n, const dfl_value* x, const dfl_value* y, dfl_value* d_out, dfl_value* work, void* stream);
+void dfl_dnrm2(dfl_index n, const dfl_value* x, dfl_value* d_out, dfl_value* work, void* stream);
+/* x *= 1 / *d_scale  (cublasDscal with the reciprocal of a device-resident norm, krylov.c:130-131,235-237) */
+void dfl_dscal_inv_dev(dfl_index n, const dfl_value* d_scale, dfl_value* x, void* stream);
+
+/* ---- fused classical Gram-Schmidt (replaces the two cublasDgemv of krylov.c:166-183
+ *      and the Dnrm2 of :230).
+ *   dfl_cgs_dots   : d_h[j] = Q[:,j] . w, j < ncol  (one pass over Q[:,0:ncol] and ~ncol/16 passes over w)
+ *   dfl_cgs_update : w -= Q[:,0:ncol] h ; *d_nrm = ||w||_2   (one pass over Q, w read+written once)
+ * Q is column-major with leading dimension ldq.  `work` >= dfl_cgs_work_size(n, ncol) doubles. */
+int64_t dfl_cgs_work_size(dfl_index n, dfl_index ncol);
+void dfl_cgs_dots(dfl_index n, dfl_index ncol, const dfl_value* Q, int64_t ldq, const dfl_value* w, dfl_value* d_h,
+                  dfl_value* work, void* stream);
+void dfl_cgs_update(dfl_index n, dfl_index ncol, const dfl_value* Q, int64_t ldq, const dfl_value* d_h, dfl_value* w,
+                    dfl_value* d_nrm, int take_sqrt, dfl_value* work, void* stream);
+void dfl_dsqrt_dev(dfl_value* d_val, void* stream); /* *d_val = sqrt(*d_val) */
+/* y = Q[:,0:ncol] c  (cublasDgemv OP_N of krylov.c:304-311) */
+void dfl_gemv_n(dfl_index n, dfl_index ncol, const dfl_value* Q, int64_t ldq, const dfl_value* d_c, dfl_value* y, void* stream);
+
+/* ---- GMRES small recurrences, device resident (replaces cublasDrot x k, Drotg,
+ *      cudaMemset(8B), GMRESResidualUpdatePrivate of krylov.c:256-277, krylov_util.cu:5-19).
+ * Column `iter` of H (leading dimension ldh) holds h[0..iter]; *d_nrm = ||w|| becomes h[iter+1].
+ * d_res_hist[iter] = |beta[iter+1]|. */
+void dfl_gmres_givens(dfl_index iter, const dfl_value* d_nrm, dfl_value* d_H, dfl_index ldh, dfl_value* d_gv,
+                      dfl_value* d_beta, dfl_value* d_res_hist, void* stream);
+/* back substitution H[0:m,0:m] y = beta[0:m] in place on beta (cublasDtrsv, krylov.c:297-301) */
+void dfl_gmres_trsv(dfl_index m, const dfl_value* d_H, dfl_index ldh, dfl_value* d_beta, void* stream);
+void GMRESResidualUpdatePrivate(dfl_value* beta, dfl_value* gv); /* same symbol as krylov_util.cu:22-24 */
+
+/* ---- block-CSR SpMV (replaces scal + 4 x cusparseSpMV, src/matrix.c:101-165,471-497):
+ *      y[0:4N] = alpha * A * x[0:4N] + beta * y[0:4N] */
+void dfl_bcsr_spmv(dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val, dfl_value alpha,
+                   const dfl_value* x, dfl_value beta, dfl_value* y, void* stream);
+/* scalar CSR SpMV for the reference-layout sub-matrices (cusparseSpMV, matrix.c:151-162) */
+void dfl_csr_spmv(dfl_index nrow, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val, dfl_value alpha,
+                  const dfl_value* x, dfl_value beta, dfl_value* y, void* stream);
+
+/* ---- preconditioner (src/pc.c:44-147, src/krylov.c:439-453):
+ *  setup : dinv33[9N] = image of inv(D_uu)^T as the reference stores it (row-major extract,
+ *          column-major inverse, Q7), dinv1[N] = 1 / A_pp diagonal
+ *  apply : y[0:3N] = inv(D)^T x, y[3N:4N] = x * dinv1, y[4N:n] = x (PCNone sections) */
+void dfl_pc_jacobi_setup(dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val,
+                         dfl_value* dinv33, dfl_value* dinv1, void* stream);
+void dfl_pc_jacobi_apply(dfl_index N, dfl_index n, const dfl_value* dinv33, const dfl_value* dinv1, const dfl_value* x,
+                         dfl_value* y, void* stream);
+/* same, fused with the normalisation of the incoming Krylov vector:
+ *   q = w / *d_nrm (stored to q_out), y = M^{-1} q */
+void dfl_pc_jacobi_apply_scaled(dfl_index N, dfl_index n, const dfl_value* dinv33, const dfl_value* dinv1, const dfl_value* w,
+                                const dfl_value* d_nrm, dfl_value* q_out, dfl_value* y, void* stream);
+/* stand-alone pieces of the same preconditioner (generic PC tree):
+ *  dfl_block3_invert : in place, row-major 3x3 blocks -> the reference's post-getri memory image (pc.c:75-77)
+ *  dfl_block3_apply  : cublasDgemvStridedBatched(OP_N) on that image (pc.c:104-112) */
+void dfl_block3_invert(dfl_index N, dfl_value* diag33, void* stream);
+void dfl_block3_apply(dfl_index N, const dfl_value* dinv33, const dfl_value* x, dfl_value* y, void* stream);
+/* diagonal extraction with the reference's semantics (matrix_impl.cu:25-44, 642-683) */
+void dfl_bcsr_get_diag(dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val,
+                       dfl_value* diag33_rowmajor /*9N or NULL*/, dfl_value* diag_p /*N or NULL*/,
+                       dfl_value* diag_u_scalar /*3N or NULL*/, void* stream);
+
+/* ---- layout conversion block CSR <-> reference FS layout (parity tests, export) */
+void dfl_block_export_fs(dfl_index N, const dfl_index* row_ptr, const dfl_value* val, dfl_value* A00, dfl_value* A01,
+                         dfl_value* A10, dfl_value* A11, void* stream);
+void dfl_block_import_fs(dfl_index N, const dfl_index* row_ptr, dfl_value* val, const dfl_value* A00, const dfl_value* A01,
+                         const dfl_value* A10, const dfl_value* A11, void* stream);
+
+/* ---- Dirichlet (src/dirichlet_impl.cu:15-36, src/matrix_impl.cu:6-23, src/matrix.c:449-469) */
+void ApplyBCVecNodalGPU(dfl_value* b, dfl_index n_bc_node, const dfl_index* bc_node, dfl_index shape, dfl_index init);
+void GetRowFromNodeGPU(dfl_index n, dfl_index* row, dfl_index shape, dfl_index init);
+void GetNodeFromRowGPU(dfl_index n, dfl_index* node, dfl_index shape);
+void dfl_dirichlet_vec(dfl_value* b, dfl_index n_bnode, const dfl_index* bnode, dfl_index shape, dfl_index comp, void* stream);
+/* rows (node*3+comp) of the block matrix <- diag * unit row (velocity part), pressure column part <- 0 */
+void dfl_bcsr_zero_rows(dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind, dfl_value* val, dfl_index n_bnode,
+                        const dfl_index* bnode, dfl_index comp, dfl_value diag, void* stream);
+/* reference-layout launcher, same symbol/signature as matrix_impl.h:10-12 (Q3-safe) */
+void MatrixCSRZeroRowGPU(dfl_value* matval, dfl_index num_row, dfl_index num_col, const dfl_index* row_ptr,
+                         const dfl_index* col_ind, dfl_index n, const dfl_index* row, dfl_index shift, dfl_value diag);
+void MatrixCSRGetDiagGPU(const dfl_value* val, const dfl_index* row_ptr, const dfl_index* col_ind, dfl_value* diag,
+                         dfl_index num_row);
+void MatrixGetDiagBlockGPU(const dfl_value* matval, dfl_index block_size, dfl_index num_row, dfl_index num_col,
+                           const dfl_index* row_ptr, const dfl_index* col_idx, dfl_value* diag_block, int lda, int stride);
+void SetValGPU(dfl_value* val, dfl_index n, dfl_value alpha);
+
+/* ---- sparsity pattern (host algorithm in the reference: src/csr.c:81-190; expansion src/csr_impl.cu:24-59) */
+/* counts per-row unique neighbours into row_len[N]; *d_overflow != 0 if a row exceeds 64 (csr.c:63 ASSERT) */
+void dfl_pattern_count(dfl_index N, const dfl_index* ien, const dfl_index* v2e_row, const dfl_index* v2e_col,
+                       dfl_index* row_len, dfl_index* d_overflow, void* stream);
+void dfl_pattern_fill(dfl_index N, const dfl_index* ien, const dfl_index* v2e_row, const dfl_index* v2e_col,
+                      const dfl_index* row_ptr, dfl_index* col_ind, void* stream);
+/* exclusive scan of len[n] into ptr[n+1] (thrust::inclusive_scan, color_impl.cu:35); temp from dfl_scan_temp_bytes */
+int64_t dfl_scan_temp_bytes(dfl_index n);
+void dfl_exclusive_scan_i32(dfl_index n, const dfl_index* len, dfl_index* ptr, void* temp, int64_t temp_bytes, void* stream);
+/* ExpandCSRByBlockSize on raw arrays (csr_impl.cu:126-156), last row_ptr entry written (Q3 fix) */
+void dfl_csr_expand(dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind, dfl_index br, dfl_index bc,
+                    dfl_index* new_row_ptr, dfl_index* new_col_ind, void* stream);
+/* (elem,a,b) -> nodal nonzero index, replaces the per-thread linear col_ind search of matrix_impl.cu:407-411 */
+void dfl_elem_nzmap(dfl_index T, const dfl_index* ien_b, const dfl_index* row_ptr, const dfl_index* col_ind,
+                    dfl_index* nzmap_b, void* stream);
+
+/* ---- coloring + batching (src/color_impl.cu:17-255, src/indexing.cu:92-102, src/Mesh.c:165-206) */
+void GenerateV2EMapRowTetGPU(const dfl_index* ien, dfl_index num_elem, dfl_index num_node, dfl_index* row_ptr);
+void GenerateV2EMapColTetGPU(const dfl_index* ien, dfl_index num_elem, dfl_index num_node, const dfl_index* row_ptr,
+                             dfl_index* col_idx);
+void GenerateRandomColor(dfl_index* color, dfl_index num_elem, dfl_index max_color); /* XORWOW(1234), LEGACY ordering */
+void ColorElementJPLTetGPU(const dfl_index* ien, const dfl_index* row_ptr, const dfl_index* col_ind, dfl_index max_color,
+                           dfl_index* color, dfl_index num_elem);
+void GetMaxColorGPU(const dfl_index* color, dfl_index num_elem, dfl_index* h_max_color);
+dfl_index CountValueColorLegacy(const dfl_index* data, dfl_index n, dfl_index value);
+void FindValueColor(const dfl_index* data, dfl_index n, dfl_index value, dfl_index* result);
+/* all colors at once: stable counting sort of element ids by color.
+ * h_batch_offset[num_color+1] (host), batch_ind[T] (device). Synchronises. */
+void dfl_color_batches(const dfl_index* color, dfl_index T, dfl_index num_color, dfl_index* h_batch_offset,
+                       dfl_index* batch_ind);
+/* ien_b[i*4+a] = ien[batch_ind[i]*4+a] : batch-ordered connectivity for streaming reads */
+void dfl_gather_ien(dfl_index T, const dfl_index* ien, const dfl_index* batch_ind, dfl_index* ien_b, void* stream);
+/* number of adjacent equal-priority pairs (Q1 diagnostic); synchronises */
+dfl_index dfl_count_priority_ties(const dfl_index* ien, dfl_index T, const dfl_index* v2e_row, const dfl_index* v2e_col,
+                                  const dfl_index* prio);
+
+/* ---- element assembly, one launch per color batch (src/assemble.cu:1559-1738 chain fused).
+ *  ien_b / nzmap_b point at the first element of the batch (batch-ordered arrays). */
+void dfl_assemble_tet_lhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_index* nzmap_b, const dfl_value* xg,
+                          const dfl_value* wgalpha, dfl_value* val, void* stream);
+void dfl_assemble_tet_rhs(dfl_index batch_size, const dfl_index* ien_b, dfl_index N, const dfl_value* xg,
+                          const dfl_value* wgalpha, const dfl_value* dwgalpha, dfl_value* F, void* stream);
+/* weak-BC faces of one color (src/assemble.cu:1764-1964): face list entries index f2e/forn of the group */
+void dfl_assemble_face(dfl_index n_face, const dfl_index* face_list, const dfl_index* f2e, const dfl_index* forn,
+                       const dfl_index* ien, dfl_index N, const dfl_value* xg, const dfl_value* wgalpha,
+                       const dfl_value* dwgalpha, dfl_value* F /*or NULL*/, const dfl_index* row_ptr, const dfl_index* col_ind,
+                       dfl_value* val /*or NULL*/, void* stream);
+
+/* ---- DEM contact sweep (build-defined; the reference's Particle.c holds storage only) */
+void dfl_dem_cell_index(dfl_index P, const dfl_value* coord, dfl_value cell, dfl_index ncell, dfl_index* cell_id, void* stream);
+void dfl_dem_sort_by_cell(dfl_index P, dfl_index* cell_id, dfl_index* order, dfl_index ncell3, dfl_index* cell_start);
+void dfl_dem_forces(dfl_index P, const dfl_value* coord, const dfl_value* vel, dfl_value radius, dfl_value mass, dfl_value kn,
+                    dfl_value gamma_n, dfl_value cell, dfl_index ncell, const dfl_index* order, const dfl_index* cell_start,
+                    dfl_value* acc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEDFLOW_KERNELS_H */

@@ -1,0 +1,73 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads (no
+compute calls -- there is no GPU here) and exports every symbol declared in
+include/dedflow_kernels.h and include/dedflow.h."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    subprocess.check_call(["make", "-s", "-j8", "-C", ROOT])
+    p = os.path.join(ROOT, "dedflow_amd", "libdedflow.so")
+    assert os.path.exists(p)
+    return p
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set()
+    for mm in re.finditer(r"^[A-Za-z_][\w\s\*]*?\b([A-Za-z_]\w*)\s*\(", txt, flags=re.M):
+        name = mm.group(1)
+        line = txt[txt.rfind("\n", 0, mm.start()) + 1: mm.end()]
+        if line.lstrip().startswith(("#", "typedef", "static", "return", "while", "if")) or "(*" in line:
+            continue
+        names.add(name)
+    return names
+
+
+def test_every_declared_kernel_symbol_is_exported(libpath):
+    lib = ctypes.CDLL(libpath)
+    missing = [n for n in sorted(_declared("dedflow_kernels.h")) if not hasattr(lib, n)]
+    # DEM sweep is declared ahead of its implementation round; everything else must resolve
+    missing = [n for n in missing if not n.startswith("dfl_dem_")]
+    assert not missing, missing
+
+
+def test_object_api_symbols_exported(libpath):
+    lib = ctypes.CDLL(libpath)
+    must = ["Init", "Finalize", "GlobalContextGet", "GetDefaultAllocator", "Mesh3DCreate", "Mesh3DDestroy",
+            "Mesh3DGenerateColorBatch", "Mesh3DSetBound", "ColorMeshTet", "GetMaxColor", "CSRAttrCreate", "CSRAttrCreateBlock",
+            "CSRAttrDestroy", "MatrixCreateTypeCSR", "MatrixCreateTypeFS", "MatrixSetup", "MatrixZero", "MatrixZeroRow",
+            "MatrixAMVPBY", "MatrixMatVec", "MatrixGetDiag", "MatrixDestroy", "VecAXPY", "VecPointwiseMult", "VecPointwiseInv",
+            "DirichletCreate", "DirichletApplyVec", "DirichletApplyMat", "DirichletDestroy", "PCCreateNone", "PCCreateJacobi",
+            "PCCreateDecomposition", "PCSetup", "PCApply", "PCDestroy", "KrylovCreateGMRES", "KrylovCreateCG", "KrylovSolve",
+            "KrylovDestroy", "AssembleSystemTet", "AssembleSystemTetFace", "AssembleSystem"]
+    missing = [n for n in must if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_product_never_references_the_oracle():
+    """The product path must not import, link or execute anything under oracle/."""
+    bad = []
+    for base in ("dedflow_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".c", ".h", ".hpp", ".hip")):
+                    if re.search(r"\boracle\b|\borc\b|liboracle", open(os.path.join(dp, f)).read()):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from dedflow_amd import api
+    monkeypatch.setattr(api, "_LIB", None)
+    monkeypatch.setattr(api, "lib_path", lambda: str(tmp_path / "nope.so"))
+    with pytest.raises(api.MissingExtension):
+        api.lib()

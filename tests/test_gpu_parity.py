@@ -1,0 +1,284 @@
+"""GPU parity tests: the HIP path (through the C ABI / C host API in
+dedflow_amd/libdedflow.so) against the CPU oracle on the same seeded inputs, and
+against the committed golden fixtures.
+
+Bars (BASELINE.json north_star): indexing / coloring / batching / patterns bit-exact;
+assembled values, F and Krylov residuals within 1e-10 relative (fp64).  "Relative"
+is taken against the largest magnitude of the array being compared (entries that
+cancel to ~0 cannot be compared entry-relative).
+The oracle itself is "parity unpinned" w.r.t. the real reference (no runnable
+reference, no fixtures -- SURVEY.md F7).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from dedflow_amd.meshgen import kuhn_cube, single_tet, synthetic_fields
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-10
+
+
+def close(a, b, rtol=RTOL):
+    scale = max(np.abs(b).max(), 1e-300)
+    err = np.abs(a - b).max() / scale
+    return err <= rtol, err
+
+
+@pytest.fixture(scope="module")
+def api():
+    from dedflow_amd import api as A
+    A.lib()  # raises if the HIP library is missing: no fallback
+    return A
+
+
+@pytest.fixture(scope="module", params=[4, 12])
+def case(request, api, oracle_lib):
+    m = kuhn_cube(request.param, jitter=0.2)
+    S = oracle_lib.System(m)
+    P = api.Problem(m)
+    wg, dwg = synthetic_fields(m)
+    yield m, S, P, wg, dwg
+    P.close()
+
+
+def test_library_exports_and_loads(api):
+    assert api.lib().dfl_abi_version() == 1
+
+
+def test_xorwow_priorities_bit_exact(api, oracle_lib):
+    n = 3 * 4096 + 123
+    d = api.DeviceArray(n, np.int32)
+    api.lib().GenerateRandomColor(d.ptr, n, 256)
+    api.sync()
+    assert np.array_equal(d.numpy(), oracle_lib.priorities(n))
+
+
+def test_pattern_bit_exact(case):
+    _, S, P, _, _ = case
+    rp, ci = P.pattern()
+    assert np.array_equal(rp, S.rp11) and np.array_equal(ci, S.ci11)
+    for attr, (orp, oci) in ((P.spy3x3, (S.rp33, S.ci33)), (P.spy3x1, (S.rp31, S.ci31)), (P.spy1x3, (S.rp13, S.ci13))):
+        rp, ci = P.pattern(attr)
+        assert np.array_equal(rp, orp) and np.array_equal(ci, oci)  # incl. the Q3-fixed last entry
+
+
+def test_coloring_and_batches_bit_exact(case):
+    m, S, P, _, _ = case
+    assert S.num_ties == 0  # tie-free => index tie-break == reference '<' (Q1)
+    assert P.num_color == S.num_color
+    assert np.array_equal(P.color(), S.color)
+    assert np.array_equal(P.batch_offset(), S.batch_offset)
+    assert np.array_equal(P.batch_ind(), S.batch_ind)
+
+
+def test_assemble_tet_matches_oracle(case, api):
+    m, S, P, wg, dwg = case
+    dwg_d, wg_d = api.DeviceArray.from_numpy(dwg), api.DeviceArray.from_numpy(wg)
+    F_d = api.DeviceArray(6 * S.N)
+    api.lib().MatrixZero(P.J)
+    P.assemble_tet(wg_d, dwg_d, F_d, want_J=True)
+    api.sync()
+    F = np.zeros(6 * S.N)
+    vals = S.new_values()
+    S.assemble_tet(wg, dwg, F, vals)
+    ok, err = close(F_d.numpy(), F)
+    assert ok, f"F rel err {err:.3e}"
+    for name, g, o in zip(("A00", "A01", "A10", "A11"), P.export_values(), vals):
+        ok, err = close(g, o)
+        assert ok, f"{name} rel err {err:.3e}"
+
+
+def test_assemble_face_matches_oracle(case, api):
+    m, S, P, wg, dwg = case
+    dwg_d, wg_d = api.DeviceArray.from_numpy(dwg), api.DeviceArray.from_numpy(wg)
+    F_d = api.DeviceArray(6 * S.N)
+    api.lib().MatrixZero(P.J)
+    P.assemble_face(wg_d, dwg_d, F_d, want_J=True)
+    api.sync()
+    F = np.zeros(6 * S.N)
+    vals = S.new_values()
+    S.assemble_face(wg, dwg, F, vals)
+    assert np.abs(F).max() > 0
+    ok, err = close(F_d.numpy(), F)
+    assert ok, f"F rel err {err:.3e}"
+    for name, g, o in zip(("A00", "A01", "A10", "A11"), P.export_values(), vals):
+        ok, err = close(g, o)
+        assert ok, f"{name} rel err {err:.3e}"
+
+
+def _assembled(case, api):
+    m, S, P, wg, dwg = case
+    dwg_d, wg_d = api.DeviceArray.from_numpy(dwg), api.DeviceArray.from_numpy(wg)
+    F_d = api.DeviceArray(6 * S.N)
+    P.assemble_system(wg_d, dwg_d, F_d, want_J=False)
+    P.assemble_system(wg_d, dwg_d, None, want_J=True)
+    api.sync()
+    F, vals = S.assemble_system(wg, dwg, True, True)
+    return F_d, F, vals
+
+
+def test_assemble_system_with_dirichlet(case, api):
+    m, S, P, wg, dwg = case
+    F_d, F, vals = _assembled(case, api)
+    Fg = F_d.numpy()
+    ok, err = close(Fg, F)
+    assert ok, f"F rel err {err:.3e}"
+    assert np.all(Fg[4 * S.N:] == 0.0)
+    gv = P.export_values()
+    for name, g, o in zip(("A00", "A01", "A10", "A11"), gv, vals):
+        ok, err = close(g, o)
+        assert ok, f"{name} rel err {err:.3e}"
+    # Dirichlet rows are exactly unit rows / zero RHS (bit-exact, no tolerance)
+    A = S.to_scipy(gv).tocsr()
+    for group, bctype in api.REFERENCE_BCS:
+        for ic, t in enumerate(bctype):
+            if t != 1:
+                continue
+            for node in S.bnodes(group)[::7]:
+                r = node * 3 + ic
+                row = A.getrow(r)
+                assert row[0, r] == 1.0 and row.nnz - (row.data == 0).sum() == 1
+                assert Fg[r] == 0.0
+
+
+def test_spmv_matches_oracle(case, api):
+    m, S, P, wg, dwg = case
+    _, _, vals = _assembled(case, api)
+    x = np.random.default_rng(0).normal(size=6 * S.N)
+    x_d = api.DeviceArray.from_numpy(x)
+    y_d = api.DeviceArray.from_numpy(np.full(6 * S.N, 7.0))
+    P.matvec(x_d, y_d)
+    api.sync()
+    y = S.matvec(vals, x)
+    yg = y_d.numpy()
+    ok, err = close(yg[:4 * S.N], y[:4 * S.N])
+    assert ok, f"SpMV rel err {err:.3e}"
+    assert np.all(yg[4 * S.N:] == 7.0)  # [4N,6N) untouched (Q5)
+    # alpha/beta form: y = -A x + y  (krylov.c:116)
+    y0 = np.random.default_rng(1).normal(size=6 * S.N)
+    y_d.upload(y0)
+    api.lib().MatrixAMVPBY(P.J, -1.0, x_d.ptr, 1.0, y_d.ptr)
+    api.sync()
+    ref = y0.copy()
+    S.amvpby(vals, -1.0, x, 1.0, ref)
+    ok, err = close(y_d.numpy()[:4 * S.N], ref[:4 * S.N])
+    assert ok, f"AMVPBY rel err {err:.3e}"
+
+
+def test_jacobi_pc_matches_oracle(case, api):
+    m, S, P, wg, dwg = case
+    _, _, vals = _assembled(case, api)
+    N = S.N
+    d33, d1 = api.DeviceArray(9 * N), api.DeviceArray(N)
+    a = P.spy1x1.contents
+    api.lib().dfl_pc_jacobi_setup(N, a.row_ptr, a.col_ind, P.block_values().ptr, d33.ptr, d1.ptr, None)
+    r = np.random.default_rng(2).normal(size=6 * N)
+    r_d, z_d = api.DeviceArray.from_numpy(r), api.DeviceArray(6 * N)
+    api.lib().dfl_pc_jacobi_apply(N, 6 * N, d33.ptr, d1.ptr, r_d.ptr, z_d.ptr, None)
+    api.sync()
+    o33, o1 = S.pc_setup(vals)
+    ok, err = close(d33.numpy(), o33, 1e-9)  # closed-form vs pivoted-LU inverse
+    assert ok, f"dinv33 rel err {err:.3e}"
+    z = S.pc_apply(o33, o1, r)
+    ok, err = close(z_d.numpy(), z, 1e-9)
+    assert ok, f"PC apply rel err {err:.3e}"
+
+
+def test_cgs_kernels(api):
+    L = api.lib()
+    rng = np.random.default_rng(3)
+    n, k = 10007 * 2, 37
+    Q = rng.normal(size=(k, n))
+    w = rng.normal(size=n)
+    Qd, wd = api.DeviceArray.from_numpy(Q.reshape(-1)), api.DeviceArray.from_numpy(w)
+    h, nrm = api.DeviceArray(k), api.DeviceArray(1)
+    work = api.DeviceArray(int(L.dfl_cgs_work_size(n, k)) + 2048)
+    L.dfl_cgs_dots(n, k, Qd.ptr, n, wd.ptr, h.ptr, work.ptr, None)
+    L.dfl_cgs_update(n, k, Qd.ptr, n, h.ptr, wd.ptr, nrm.ptr, 1, work.ptr, None)
+    api.sync()
+    href = Q @ w
+    wref = w - Q.T @ href
+    assert np.allclose(h.numpy(), href, rtol=1e-12, atol=1e-12 * np.abs(href).max())
+    assert np.allclose(wd.numpy(), wref, rtol=0, atol=1e-12 * np.abs(wref).max())
+    assert np.isclose(nrm.numpy()[0], np.linalg.norm(wref), rtol=1e-13)
+
+
+def test_gmres_matches_oracle(case, api):
+    m, S, P, wg, dwg = case
+    F_d, F, vals = _assembled(case, api)
+    x_d = api.DeviceArray(6 * S.N)
+    it, r0, hist, conv = P.solve(x_d, F_d)
+    xo, ho, r0o, ito = S.gmres(vals, F)
+    assert it == ito
+    assert abs(r0 - r0o) <= 1e-12 * r0o
+    # residual history: tolerance grows with the iteration count (CGS reduction order, SURVEY hard part vii)
+    k = np.arange(1, it + 1)
+    assert np.all(np.abs(hist - ho) <= 1e-10 * r0o * np.maximum(1.0, k / 10.0)), np.abs(hist - ho).max() / r0o
+    xg = x_d.numpy()
+    ok, err = close(xg[:4 * S.N], xo[:4 * S.N], 1e-8)
+    assert ok, f"solution rel err {err:.3e}"
+    assert np.all(xg[4 * S.N:] == 0.0)
+
+
+@pytest.mark.parametrize("name", ["cube_M4", "cube_M12"])
+def test_golden_fixtures(name, api):
+    """HIP path against the committed fixtures only (no oracle call)."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    m = kuhn_cube(int(g["M"]), jitter=float(g["jitter"]))
+    P = api.Problem(m)
+    try:
+        assert np.array_equal(P.color(), g["color"])
+        assert np.array_equal(P.batch_offset(), g["batch_offset"])
+        assert np.array_equal(P.batch_ind(), g["batch_ind"])
+        rp, ci = P.pattern()
+        assert np.array_equal(rp, g["row_ptr"]) and np.array_equal(ci, g["col_ind"])
+        wg, dwg = synthetic_fields(m)
+        wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+        F_d = api.DeviceArray(6 * P.N)
+        P.assemble_system(wg_d, dwg_d, F_d, want_J=False)
+        P.assemble_system(wg_d, dwg_d, None, want_J=True)
+        api.sync()
+        ok, err = close(F_d.numpy(), g["F"])
+        assert ok, err
+        vals = P.export_values()
+        for k, v in zip(("A00", "A01", "A10", "A11"), vals):
+            if name == "cube_M4":
+                ok, err = close(v, g[k])
+            else:
+                ok, err = close(v[::37], g[k + "_sample"], 1e-10 * np.abs(v).max() / max(np.abs(g[k + "_sample"]).max(), 1e-300))
+                assert np.isclose(np.dot(v, v), g[k + "_sum"][2], rtol=1e-9)
+            assert ok, (k, err)
+        x_d = api.DeviceArray(6 * P.N)
+        it, r0, hist, _ = P.solve(x_d, F_d)
+        assert it == int(g["gmres_it"])
+        assert np.all(np.abs(hist - g["gmres_hist"]) <= 1e-9 * float(g["gmres_r0"]))
+    finally:
+        P.close()
+
+
+def test_single_tet_all_faces(api, oracle_lib):
+    """DBG_TET-like case (src/main.c:357-361): one element, face assembly on a chosen group."""
+    m = single_tet()
+    S = oracle_lib.System(m)
+    P = api.Problem(m, bcs=[])
+    try:
+        rng = np.random.default_rng(5)
+        wg, dwg = rng.normal(size=6 * S.N), rng.normal(size=6 * S.N)
+        wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+        F_d = api.DeviceArray(6 * S.N)
+        api.lib().MatrixZero(P.J)
+        P.assemble_tet(wg_d, dwg_d, F_d, want_J=True)
+        api.sync()
+        F = np.zeros(6 * S.N)
+        vals = S.new_values()
+        S.assemble_tet(wg, dwg, F, vals)
+        ok, err = close(F_d.numpy(), F)
+        assert ok, err
+        for g, o in zip(P.export_values(), vals):
+            ok, err = close(g, o)
+            assert ok, err
+    finally:
+        P.close()
