@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- DEDFlow hot path on MI355X.
+
+One "step" = one Newton linearisation of the reference driver (src/main.c:157-279)
+on a synthetic Kuhn-cube tet mesh, inputs resident in HBM:
+    AssembleSystem(F)  colored RHS assembly + weak-BC faces + Dirichlet      (src/main.c:124)
+    AssembleSystem(J)  zero + colored LHS assembly + faces + Dirichlet rows  (src/main.c:160)
+    KrylovSolve        PC setup + `--gmres-its` right-preconditioned GMRES iterations
+                       (block-Jacobi PC tree of krylov.c:439-453; tolerances 0 so the
+                       iteration count is fixed and the work per step is constant)
+value = (4N active u,p DOFs) / (seconds per step)  -- whole-job DOFs assembled and solved per second.
+Per-kernel launch durations are measured live with hipEvents on the library stream
+(DflProfile*, dedflow_amd/host/runtime.c); roofline.achieved uses the ALGORITHMIC
+bytes of SURVEY.md 8(d) / BASELINE.md 3.
+
+N=1 workload: the 10M-tet cube (M=119) BASELINE.json's metric is quoted on.
+N>1: the same mesh, element-partitioned over N ranks (strong scaling), halo exchange +
+all-reduce through torch.distributed (backend nccl = RCCL).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+TAGS = {"spmv": 0, "cgs_dots": 1, "cgs_update": 2, "pc_apply": 3, "asm_lhs": 4, "asm_rhs": 5, "face": 6}
+
+
+def algorithmic_bytes(N, T, nnz1, its):
+    """bytes per launch (per unit) of each kernel class."""
+    n4 = 4 * N
+    return {
+        "spmv": 132.0 * nnz1 + 4.0 * (N + 1) + 64.0 * N,                      # per matvec
+        "asm_lhs": T * (16.0 + 4.0 + 4096.0) + 120.0 * N,                    # per J assembly (all colors)
+        "asm_rhs": T * (20.0 + 384.0) + 120.0 * N,                           # per F assembly
+        "pc_apply": (9 + 1) * 8.0 * N + 2 * 8.0 * n4,                        # per apply
+        "cgs": [2 * 8.0 * n4 * (k + 1) + 24.0 * n4 for k in range(its)],     # dots+update of step k
+    }
+
+
+def cpu_baseline(M_sample, its):
+    """The CPU oracle (oracle/liboracle.so, single thread, kind "port") on a bounded sample
+    of the same step: same mesh family, smaller M.  Test infrastructure used as the
+    reported baseline only -- never on the product path."""
+    from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
+    from oracle import orc
+    m = kuhn_cube(M_sample, jitter=0.2)
+    wg, dwg = synthetic_fields(m)
+    S = orc.System(m)
+    t0 = time.perf_counter()
+    F, _ = S.assemble_system(wg, dwg, True, False)
+    tF = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, vals = S.assemble_system(wg, dwg, False, True)
+    tJ = time.perf_counter() - t0
+    x = np.random.default_rng(0).normal(size=6 * S.N)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        S.matvec(vals, x)
+    tS = (time.perf_counter() - t0) / 5
+    t0 = time.perf_counter()
+    S.gmres(vals, F, maxit=its, atol=0.0, rtol=0.0)
+    tG = time.perf_counter() - t0
+    step = tF + tJ + tG
+    spmv_bytes = 132.0 * S.nnz1 + 4.0 * (S.N + 1) + 64.0 * S.N
+    return {
+        "value": 4.0 * S.N / step, "unit": "DOF/s", "cores": 1, "kind": "port",
+        "sample": f"Kuhn cube M={M_sample} ({S.T} tets, {S.N} nodes), same step (F + J assembly, {its} GMRES its), "
+                  f"oracle/liboracle.so single thread",
+        "assemble_J_s": tJ, "assemble_F_s": tF, "gmres_s": tG, "spmv_s": tS,
+        "assemble_J_dofs_per_s": 4.0 * S.N / tJ, "spmv_GBps": spmv_bytes / tS / 1e9,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--M", type=int, default=119, help="cells per cube edge (119 -> 10.1M tets)")
+    ap.add_argument("--gmres-its", type=int, default=40)
+    ap.add_argument("--cpu-M", type=int, default=40, help="cube size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--jitter", type=float, default=0.2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        from dedflow_amd import dist_bench
+        return dist_bench.run(args, rank, world, local_rank)
+
+    from dedflow_amd import api
+    from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
+    L = api.lib()
+    api.hip().hipSetDevice(local_rank)
+    L.DflProfileEnable.argtypes = [C.c_int]
+    L.DflProfileCollect.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.DflProfileCollect.restype = C.c_int
+
+    t_setup = time.perf_counter()
+    mesh = kuhn_cube(args.M, jitter=args.jitter)
+    wg, dwg = synthetic_fields(mesh)
+    its = args.gmres_its
+    P = api.Problem(mesh, maxit=its, atol=0.0, rtol=0.0, quiet=True)
+    N, T, nnz1 = P.N, P.T, P.nnz1
+    wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+    F_d, x_d = api.DeviceArray(6 * N), api.DeviceArray(6 * N)
+    api.sync()
+    t_setup = time.perf_counter() - t_setup
+
+    def step():
+        P.assemble_system(wg_d, dwg_d, F_d, want_J=False)
+        P.assemble_system(wg_d, dwg_d, None, want_J=True)
+        x_d.zero()
+        return P.solve(x_d, F_d)
+
+    for _ in range(args.warmup):
+        step()
+    api.sync()
+    L.DflProfileEnable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        it, r0, hist, _ = step()
+    api.sync()
+    t_total = time.perf_counter() - t0
+    ms_per_step = 1e3 * t_total / args.steps
+
+    prof = {}
+    for name, tag in TAGS.items():
+        tot, mn = C.c_double(0), C.c_double(0)
+        cnt = L.DflProfileCollect(tag, C.byref(tot), C.byref(mn))
+        prof[name] = (cnt, tot.value, mn.value)
+    L.DflProfileEnable(0)
+
+    ab = algorithmic_bytes(N, T, nnz1, its)
+    K = args.steps
+    kernels = {}
+
+    def entry(name, total_bytes, cnt, tot_ms, unit_desc):
+        if cnt == 0 or tot_ms <= 0:
+            return
+        gbps = total_bytes / (tot_ms * 1e-3) / 1e9
+        kernels[name] = {"launches": cnt, "avg_ms": tot_ms / cnt, "total_ms_per_step": tot_ms / K, "GBps": gbps,
+                         "frac_of_8TBps": gbps / HBM_PEAK_GBS, "bytes": unit_desc}
+
+    c, t, _ = prof["spmv"]; entry("spmv", ab["spmv"] * c, c, t, "132*nnz1+4(N+1)+64N per launch")
+    c, t, _ = prof["asm_lhs"]; entry("asm_lhs", ab["asm_lhs"] * K, c, t, "4116*T+120N per J assembly (one launch per color)")
+    c, t, _ = prof["asm_rhs"]; entry("asm_rhs", ab["asm_rhs"] * K, c, t, "404*T+120N per F assembly (one launch per color)")
+    c, t, _ = prof["pc_apply"]; entry("pc_apply", ab["pc_apply"] * c, c, t, "80N+64N per apply")
+    cd, td, _ = prof["cgs_dots"]; cu, tu, _ = prof["cgs_update"]
+    entry("cgs", sum(ab["cgs"]) * K, cd + cu, td + tu, "2*8*4N*(k+1)+24*4N per Arnoldi step k")
+    dominant = max(kernels, key=lambda k: kernels[k]["total_ms_per_step"])
+    kd = kernels[dominant]
+    per_launch_bytes = {"spmv": ab["spmv"], "asm_lhs": ab["asm_lhs"] * K / max(kd["launches"], 1),
+                        "asm_rhs": ab["asm_rhs"] * K / max(kd["launches"], 1), "pc_apply": ab["pc_apply"],
+                        "cgs": sum(ab["cgs"]) * K / max(kd["launches"], 1)}[dominant]
+    roofline = {"kernel": dominant, "bound": "hbm", "achieved": kd["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kd["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": kd["avg_ms"]}
+
+    cpu = cpu_baseline(args.cpu_M, its) if args.cpu_M > 0 else None
+
+    tJ = kernels.get("asm_lhs", {}).get("total_ms_per_step", 0.0)
+    tF = kernels.get("asm_rhs", {}).get("total_ms_per_step", 0.0)
+    out = {
+        "metric": "assembled DOFs/s + Krylov-SpMV GB/s (%HBM peak), 10M-tet mesh",
+        "value": 4.0 * N / (ms_per_step * 1e-3), "unit": "DOF/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"Kuhn cube M={args.M}: {T} tets, {N} nodes, nnz1={nnz1}; step = AssembleSystem(F) + "
+                               f"AssembleSystem(J) + Jacobi-PC GMRES x{its} iterations",
+                   "colors": P.num_color, "gmres_its": its, "parallelism": "1 GPU"},
+        "spmv_GBps": kernels.get("spmv", {}).get("GBps"), "spmv_frac_of_hbm_peak": kernels.get("spmv", {}).get("frac_of_8TBps"),
+        "assemble_J_dofs_per_s": (4.0 * N / (tJ * 1e-3)) if tJ else None,
+        "assemble_F_dofs_per_s": (6.0 * N / (tF * 1e-3)) if tF else None,
+        "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        "setup_s": t_setup, "gmres_residual_drop": float(hist[-1] / r0) if len(hist) else None,
+    }
+    print(json.dumps(out))
+    P.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,8 +51,8 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
         const index_type bsz = mesh->batch_offset[b + 1] - off;
         if (bsz == 0) break; /* assemble.cu:1565-1567 */
         const index_type* ien_b = x->ien_b + (size_t)off * 4;
-        if (F) dfl_assemble_tet_rhs(bsz, ien_b, N, dev->xg, wgalpha_dptr, dwgalpha_dptr, F, s);
-        if (J) dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, dev->xg, wgalpha_dptr, val, s);
+        if (F) DFL_TIMED(DFL_TAG_ASM_RHS, dfl_assemble_tet_rhs(bsz, ien_b, N, dev->xg, wgalpha_dptr, dwgalpha_dptr, F, s));
+        if (J) DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, dev->xg, wgalpha_dptr, val, s));
     }
 }
 
@@ -69,12 +69,14 @@ void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, 
     if (J) spy = block_pattern(J, &val);
     const index_type* f2e = Mesh3DBoundF2E(mesh, group);
     const index_type* forn = Mesh3DBoundFORN(mesh, group);
+    int slot = DflProfileBegin(DFL_TAG_FACE);
     for (index_type c = 0; c < mesh->num_color; ++c) { /* one launch per parent color: race-free, color order */
         index_type lo = x->face_color_offset[c], nf = x->face_color_offset[c + 1] - lo;
         if (!nf) continue;
         dfl_assemble_face(nf, x->face_list + lo, f2e, forn, dev->ien, N, dev->xg, wgalpha_dptr, dwgalpha_dptr, F,
                           spy ? spy->row_ptr : NULL, spy ? spy->col_ind : NULL, val, s);
     }
+    DflProfileEnd(slot);
 }
 
 void AssembleSystem(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, Dirichlet** bcs, index_type nbc) {

@@ -16,4 +16,13 @@ typedef struct MeshExt {
 void DflMeshPrepareFaces(Mesh3D* mesh, index_type group);
 b32 DflQuiet(void);
 
+/* profiling tags (runtime.c) */
+enum { DFL_TAG_SPMV = 0, DFL_TAG_CGS_DOTS = 1, DFL_TAG_CGS_UPDATE = 2, DFL_TAG_PC = 3, DFL_TAG_ASM_LHS = 4,
+       DFL_TAG_ASM_RHS = 5, DFL_TAG_FACE = 6, DFL_TAG_DIRICHLET = 7, DFL_TAG_SMALL = 8 };
+void DflProfileEnable(int on);
+int DflProfileBegin(int tag);
+void DflProfileEnd(int slot);
+int DflProfileCollect(int tag, double* total_ms, double* min_ms);
+#define DFL_TIMED(tag, call) do { int _s = DflProfileBegin(tag); call; DflProfileEnd(_s); } while (0)
+
 #endif

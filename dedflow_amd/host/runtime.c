@@ -110,3 +110,49 @@ void ArrayCopy(Array* dst, const Array* src, MemCopyKind kind) {
     ASSERT(dst && src && dst->len == src->len);
     HIPGUARD(hipMemcpy(dst->data, src->data, (size_t)src->len * sizeof(f64), kind));
 }
+
+/* ---- in-library kernel timing (hipEvent pairs on the library stream) --------------------
+ * bench.py brackets the timed region with these so that per-kernel launch durations are
+ * measured live, on the stream the kernels run on. */
+#define DFL_PROF_TAGS 16
+#define DFL_PROF_MAX 8192
+static int g_prof_on = 0;
+static struct { hipEvent_t a, b; int tag; } g_ev[DFL_PROF_MAX];
+static int g_ev_n = 0, g_ev_alloc = 0;
+
+void DflProfileEnable(int on) {
+    g_prof_on = on;
+    g_ev_n = 0;
+}
+int DflProfileBegin(int tag) {
+    if (!g_prof_on || g_ev_n >= DFL_PROF_MAX) return -1;
+    int i = g_ev_n++;
+    if (i >= g_ev_alloc) {
+        HIPGUARD(hipEventCreate(&g_ev[i].a));
+        HIPGUARD(hipEventCreate(&g_ev[i].b));
+        g_ev_alloc = i + 1;
+    }
+    g_ev[i].tag = tag;
+    HIPGUARD(hipEventRecord(g_ev[i].a, g_stream));
+    return i;
+}
+void DflProfileEnd(int slot) {
+    if (slot >= 0) HIPGUARD(hipEventRecord(g_ev[slot].b, g_stream));
+}
+/* sums the elapsed time of every recorded interval with this tag; synchronises */
+int DflProfileCollect(int tag, double* total_ms, double* min_ms) {
+    int count = 0;
+    double tot = 0.0, mn = 1e300;
+    HIPGUARD(hipStreamSynchronize(g_stream));
+    for (int i = 0; i < g_ev_n; ++i) {
+        if (g_ev[i].tag != tag) continue;
+        float ms = 0.f;
+        HIPGUARD(hipEventElapsedTime(&ms, g_ev[i].a, g_ev[i].b));
+        tot += ms;
+        if (ms < mn) mn = ms;
+        ++count;
+    }
+    if (total_ms) *total_ms = tot;
+    if (min_ms) *min_ms = count ? mn : 0.0;
+    return count;
+}

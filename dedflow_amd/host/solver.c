@@ -333,13 +333,14 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
        nrm[k] holds the norm Q[:,k] still has to be divided by */
     while (!converged && iter < maxit) {
         /* 2.0 tmp = inv(P) Q[:,iter]   2.2 Q[:,iter+1] = A tmp */
-        pc_apply_fused(pc, na, QCOL(iter), ex->nrm + iter, tmp);
+        DFL_TIMED(DFL_TAG_PC, pc_apply_fused(pc, na, QCOL(iter), ex->nrm + iter, tmp));
         if (dist) ex->comm.halo_exchange(ex->comm.ctx, tmp);
-        MatrixMatVec(A, tmp, QCOL(iter + 1));
+        DFL_TIMED(DFL_TAG_SPMV, MatrixMatVec(A, tmp, QCOL(iter + 1)));
         /* 3. classical Gram-Schmidt */
-        dfl_cgs_dots(na, iter + 1, Q, na, QCOL(iter + 1), HCOL(iter), ex->work, s);
+        DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 1, Q, na, QCOL(iter + 1), HCOL(iter), ex->work, s));
         if (dist) ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 1);
-        dfl_cgs_update(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), ex->nrm + iter + 1, dist ? 0 : 1, ex->work, s);
+        DFL_TIMED(DFL_TAG_CGS_UPDATE,
+                  dfl_cgs_update(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), ex->nrm + iter + 1, dist ? 0 : 1, ex->work, s));
         if (dist) {
             ex->comm.allreduce_sum(ex->comm.ctx, ex->nrm + iter + 1, 1);
             dfl_dsqrt_dev(ex->nrm + iter + 1, s);
