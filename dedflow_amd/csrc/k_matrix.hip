@@ -17,13 +17,13 @@ constexpr int BLK = 256;
 __device__ __forceinline__ long long xidx(int col, int c, long long N3) { return c < 3 ? 3LL * col + c : N3 + col; }
 
 template <bool BETA0>
-__global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I N, const I* __restrict__ rp, const I* __restrict__ ci,
+__global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I nrows, I N, const I* __restrict__ rp, const I* __restrict__ ci,
                                                        const T* __restrict__ val, T alpha, const T* __restrict__ x, T beta,
                                                        T* __restrict__ y) {
     const long long gid = (long long)blockIdx.x * BLK + threadIdx.x;
     const int row = (int)(gid >> 3);
     const int l = threadIdx.x & 7;
-    if (row >= N) return;  // whole 8-lane group leaves together
+    if (row >= nrows) return;  // whole 8-lane group leaves together
     const long long N3 = 3LL * N;
     const int r = l >> 1;
     const bool hi = (l & 1);  // false: columns (u0,u1); true: columns (u2,p)
@@ -103,9 +103,9 @@ __device__ __forceinline__ void inv3(const double* m, double* o) {
 // PCJacobiSetup (pc.c:44-85): the reference extracts D row-major, hands the 9
 // numbers to column-major LAPACK (=> inverts D^T) and keeps the column-major
 // result.  Memory image = inv(D^T) column-major = inv(D) row-major.
-__global__ __launch_bounds__(BLK) void pc_setup_kernel(I N, const I* rp, const I* ci, const T* val, T* dinv33, T* dinv1) {
+__global__ __launch_bounds__(BLK) void pc_setup_kernel(I nrows, const I* rp, const I* ci, const T* val, T* dinv33, T* dinv1) {
     const int node = blockIdx.x * BLK + threadIdx.x;
-    if (node >= N) return;
+    if (node >= nrows) return;
     const int k = find_diag(rp, ci, node);
     const T* b = val + (long long)k * 16;
     double m[9], o[9];
@@ -121,12 +121,12 @@ __global__ __launch_bounds__(BLK) void pc_setup_kernel(I N, const I* rp, const I
 
 // PCDecompositionApply (pc.c:136-147): z_u = inv(D)^T r_u (Q7), z_p = r_p * dinv1, tail copied.
 template <bool SCALED>
-__global__ __launch_bounds__(BLK) void pc_apply_kernel(I N, const T* __restrict__ dinv33, const T* __restrict__ dinv1,
+__global__ __launch_bounds__(BLK) void pc_apply_kernel(I nrows, I N, const T* __restrict__ dinv33, const T* __restrict__ dinv1,
                                                       const T* __restrict__ x, const T* __restrict__ d_nrm, T* __restrict__ q,
                                                       T* __restrict__ y) {
     const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
     const double s = SCALED ? 1.0 / d_nrm[0] : 1.0;
-    if (i < N) {
+    if (i < nrows) {
         const T* A = dinv33 + i * 9;  // column-major image: A(r,c) = A[r + 3c]
         double x0 = x[3 * i], x1 = x[3 * i + 1], x2 = x[3 * i + 2], xp = x[3LL * N + i];
         if (SCALED) {
@@ -264,12 +264,15 @@ __global__ void node_from_row_kernel(I n, I* node, I shape) {
 
 extern "C" {
 
-void dfl_bcsr_spmv(I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
-    if (N <= 0) return;
-    const int grid = ceil_div((long long)N * 8, BLK);
-    if (beta == 0.0) bcsr_spmv_kernel<true><<<grid, BLK, 0, S(stream)>>>(N, rp, ci, val, alpha, x, beta, y);
-    else bcsr_spmv_kernel<false><<<grid, BLK, 0, S(stream)>>>(N, rp, ci, val, alpha, x, beta, y);
+void dfl_bcsr_spmv_rows(I nrows, I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
+    if (nrows <= 0) return;
+    const int grid = ceil_div((long long)nrows * 8, BLK);
+    if (beta == 0.0) bcsr_spmv_kernel<true><<<grid, BLK, 0, S(stream)>>>(nrows, N, rp, ci, val, alpha, x, beta, y);
+    else bcsr_spmv_kernel<false><<<grid, BLK, 0, S(stream)>>>(nrows, N, rp, ci, val, alpha, x, beta, y);
     DFL_LAUNCH_CHECK();
+}
+void dfl_bcsr_spmv(I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
+    dfl_bcsr_spmv_rows(N, N, rp, ci, val, alpha, x, beta, y, stream);
 }
 
 void dfl_csr_spmv(I nrow, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
@@ -278,24 +281,35 @@ void dfl_csr_spmv(I nrow, const I* rp, const I* ci, const T* val, T alpha, const
     DFL_LAUNCH_CHECK();
 }
 
-void dfl_pc_jacobi_setup(I N, const I* rp, const I* ci, const T* val, T* dinv33, T* dinv1, void* stream) {
-    pc_setup_kernel<<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, rp, ci, val, dinv33, dinv1);
+void dfl_pc_jacobi_setup_rows(I nrows, const I* rp, const I* ci, const T* val, T* dinv33, T* dinv1, void* stream) {
+    if (nrows <= 0) return;
+    pc_setup_kernel<<<ceil_div(nrows, BLK), BLK, 0, S(stream)>>>(nrows, rp, ci, val, dinv33, dinv1);
     DFL_LAUNCH_CHECK();
 }
+void dfl_pc_jacobi_setup(I N, const I* rp, const I* ci, const T* val, T* dinv33, T* dinv1, void* stream) {
+    dfl_pc_jacobi_setup_rows(N, rp, ci, val, dinv33, dinv1, stream);
+}
 
-void dfl_pc_jacobi_apply(I N, I n, const T* dinv33, const T* dinv1, const T* x, T* y, void* stream) {
-    pc_apply_kernel<false><<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, dinv33, dinv1, x, nullptr, nullptr, y);
+void dfl_pc_jacobi_apply_rows(I nrows, I N, I n, const T* dinv33, const T* dinv1, const T* x, T* y, void* stream) {
+    if (nrows > 0) pc_apply_kernel<false><<<ceil_div(nrows, BLK), BLK, 0, S(stream)>>>(nrows, N, dinv33, dinv1, x, nullptr, nullptr, y);
     if (n > 4 * N)
         tail_copy_kernel<<<ceil_div((long long)n - 4LL * N, BLK), BLK, 0, S(stream)>>>(4LL * N, n, x, nullptr, nullptr, y);
     DFL_LAUNCH_CHECK();
 }
+void dfl_pc_jacobi_apply(I N, I n, const T* dinv33, const T* dinv1, const T* x, T* y, void* stream) {
+    dfl_pc_jacobi_apply_rows(N, N, n, dinv33, dinv1, x, y, stream);
+}
 
-void dfl_pc_jacobi_apply_scaled(I N, I n, const T* dinv33, const T* dinv1, const T* w, const T* d_nrm, T* q_out, T* y,
-                                void* stream) {
-    pc_apply_kernel<true><<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, dinv33, dinv1, w, d_nrm, q_out, y);
+void dfl_pc_jacobi_apply_scaled_rows(I nrows, I N, I n, const T* dinv33, const T* dinv1, const T* w, const T* d_nrm, T* q_out,
+                                     T* y, void* stream) {
+    if (nrows > 0) pc_apply_kernel<true><<<ceil_div(nrows, BLK), BLK, 0, S(stream)>>>(nrows, N, dinv33, dinv1, w, d_nrm, q_out, y);
     if (n > 4 * N)
         tail_copy_kernel<<<ceil_div((long long)n - 4LL * N, BLK), BLK, 0, S(stream)>>>(4LL * N, n, w, d_nrm, q_out, y);
     DFL_LAUNCH_CHECK();
+}
+void dfl_pc_jacobi_apply_scaled(I N, I n, const T* dinv33, const T* dinv1, const T* w, const T* d_nrm, T* q_out, T* y,
+                                void* stream) {
+    dfl_pc_jacobi_apply_scaled_rows(N, N, n, dinv33, dinv1, w, d_nrm, q_out, y, stream);
 }
 
 void dfl_block3_invert(I N, T* diag33, void* stream) {

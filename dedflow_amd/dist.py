@@ -1,0 +1,251 @@
+"""Element-partitioned multi-GPU layer: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on MI355X; "gloo" for CPU tests).
+
+The reference is single-GPU, so this is new design, not a match:
+
+* partition   RCB on tet centroids (C, DflPartitionRCB).  node owner = lowest part
+              touching the node.  A rank's local mesh = every tet touching a node
+              it owns (own tets + one halo layer), so owned matrix rows and owned
+              RHS entries are complete after a purely local colored assembly --
+              ZERO assembly communication.
+* numbering   local nodes: owned first (ascending global id), then ghosts.  SpMV
+              and the preconditioner run on the owned rows only; ghost entries of
+              every Krylov vector stay zero, so local dot products are exact
+              partial sums.
+* collectives (1) halo exchange of the SpMV input (4 dof per interface node,
+              point-to-point to the few neighbours that need it), (2) all-reduce
+              of the k+1 CGS coefficients and of ||w||^2 per GMRES iteration,
+              (3) one all-reduce for the initial residual.  All latency-bound.
+
+The numpy/torch pieces here are plumbing (index sets, buffers, collectives); all
+arithmetic on the path is in libdedflow.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from .meshgen import TetMesh
+
+
+@dataclass
+class LocalMesh:
+    mesh: TetMesh            # local connectivity / coordinates / boundary groups (local numbering)
+    n_owned: int             # local nodes [0, n_owned) are owned
+    l2g_node: np.ndarray     # local node -> global node
+    l2g_elem: np.ndarray     # local tet  -> global tet
+    ghost_owner: np.ndarray  # owner rank of each ghost node (local ids n_owned..)
+    rank: int
+    world: int
+
+
+def partition_rcb(mesh: TetMesh, num_part: int) -> np.ndarray:
+    """epart[T] through the C partitioner in libdedflow.so."""
+    from . import api
+    L = api.lib()
+    epart = np.empty(mesh.num_tet, np.int32)
+    L.DflPartitionRCB.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.DflPartitionRCB.restype = None
+    L.DflPartitionRCB(mesh.num_tet, mesh.ien.ctypes.data, mesh.xg.ctypes.data, num_part, epart.ctypes.data)
+    return epart
+
+
+def node_owner(mesh: TetMesh, epart: np.ndarray, num_part: int) -> np.ndarray:
+    """owner(node) = min part over the tets touching it."""
+    ien = mesh.ien.reshape(-1, 4)
+    owner = np.full(mesh.num_node, num_part, np.int32)
+    for p in range(num_part - 1, -1, -1):  # smaller parts overwrite larger ones
+        owner[ien[epart == p].reshape(-1)] = p
+    return owner
+
+
+def build_local(mesh: TetMesh, epart: np.ndarray, owner: np.ndarray, rank: int, world: int) -> LocalMesh:
+    ien = mesh.ien.reshape(-1, 4)
+    touches = (owner[ien] == rank).any(axis=1)
+    l2g_elem = np.nonzero(touches)[0].astype(np.int64)
+    lien_g = ien[l2g_elem]
+    nodes = np.unique(lien_g)
+    own_mask = owner[nodes] == rank
+    l2g_node = np.concatenate([nodes[own_mask], nodes[~own_mask]]).astype(np.int64)
+    n_owned = int(own_mask.sum())
+    g2l = np.full(mesh.num_node, -1, np.int64)
+    g2l[l2g_node] = np.arange(l2g_node.size)
+    e_g2l = np.full(mesh.num_tet, -1, np.int64)
+    e_g2l[l2g_elem] = np.arange(l2g_elem.size)
+    lien = g2l[lien_g].astype(np.int32)
+    xg = mesh.xg.reshape(-1, 3)[l2g_node]
+
+    node_off, elem_off = [0], [0]
+    bnodes, bf2e, bforn, bien = [], [], [], []
+    for g in range(mesh.num_bound):
+        gn = mesh.bound_node[mesh.bound_node_offset[g]:mesh.bound_node_offset[g + 1]]
+        ln = g2l[gn]
+        ln = np.sort(ln[ln >= 0]).astype(np.int32)  # every local node of the group (owned or ghost)
+        lo, hi = mesh.bound_elem_offset[g], mesh.bound_elem_offset[g + 1]
+        fe = e_g2l[mesh.bound_f2e[lo:hi]]
+        keep = fe >= 0                               # faces whose parent tet is local
+        bnodes.append(ln)
+        bf2e.append(fe[keep].astype(np.int32))
+        bforn.append(mesh.bound_forn[lo:hi][keep].astype(np.int32))
+        bien.append(g2l[mesh.bound_ien[3 * lo:3 * hi].reshape(-1, 3)[keep]].reshape(-1).astype(np.int32))
+        node_off.append(node_off[-1] + ln.size)
+        elem_off.append(elem_off[-1] + int(keep.sum()))
+    lm = TetMesh(M=mesh.M, xg=np.ascontiguousarray(xg.reshape(-1)), ien=np.ascontiguousarray(lien.reshape(-1)),
+                 bound_node_offset=np.asarray(node_off, np.int32), bound_node=np.concatenate(bnodes).astype(np.int32),
+                 bound_elem_offset=np.asarray(elem_off, np.int32), bound_ien=np.concatenate(bien).astype(np.int32),
+                 bound_f2e=np.concatenate(bf2e).astype(np.int32), bound_forn=np.concatenate(bforn).astype(np.int32))
+    return LocalMesh(lm, n_owned, l2g_node, l2g_elem, owner[l2g_node[n_owned:]].astype(np.int32), rank, world)
+
+
+def localize_vector(v: np.ndarray, lm: LocalMesh, N_global: int) -> np.ndarray:
+    """global [u|p|phi|T] vector -> local layout"""
+    g = lm.l2g_node
+    n = g.size
+    out = np.empty(6 * n)
+    out[:3 * n] = v[:3 * N_global].reshape(-1, 3)[g].reshape(-1)
+    for s in range(3):
+        out[(3 + s) * n:(4 + s) * n] = v[(3 + s) * N_global:(4 + s) * N_global][g]
+    return out
+
+
+class HaloPlan:
+    """Who sends which owned nodes to whom.  Built with one all_gather_object of the ghost
+    lists (setup time); exchange = one batch of isend/irecv per neighbour."""
+
+    def __init__(self, lm: LocalMesh, dist, device, use_host_staging: bool):
+        import torch
+        self.torch, self.dist, self.device, self.staged = torch, dist, device, use_host_staging
+        self.rank, self.world = lm.rank, lm.world
+        n = lm.l2g_node.size
+        self.n_local, self.n_owned = n, lm.n_owned
+        ghosts_g = lm.l2g_node[lm.n_owned:]
+        need = {int(q): ghosts_g[lm.ghost_owner == q] for q in np.unique(lm.ghost_owner)}
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, need)
+        g2l_owned = {}
+        own_g = lm.l2g_node[:lm.n_owned]
+        order = np.argsort(own_g)
+        self.recv_idx, self.send_idx = {}, {}
+        for q, arr in need.items():  # my ghosts owned by q, in the order I asked for them
+            loc = np.nonzero(lm.ghost_owner == q)[0] + lm.n_owned
+            self.recv_idx[q] = self._dof_index(loc, n)
+        for q in range(self.world):
+            if q == self.rank or gathered[q] is None or self.rank not in gathered[q]:
+                continue
+            want = gathered[q][self.rank]
+            pos = order[np.searchsorted(own_g, want, sorter=order)]
+            assert np.array_equal(own_g[pos], want)
+            self.send_idx[q] = self._dof_index(pos, n)
+        self.neighbours = sorted(set(self.recv_idx) | set(self.send_idx))
+        self.bytes_per_exchange = 8 * sum(int(v.numel()) for v in self.send_idx.values())
+
+    def _dof_index(self, nodes, n):
+        """flat indices of the 4 (u0,u1,u2,p) dofs of each node in the local [u|p|...] layout"""
+        nodes = np.asarray(nodes, np.int64)
+        idx = np.concatenate([3 * nodes, 3 * nodes + 1, 3 * nodes + 2, 3 * n + nodes])
+        return self.torch.as_tensor(idx, device=self.device)
+
+    def exchange(self, x):
+        """x: torch f64 tensor (local vector, on self.device); fills the ghost dofs in place."""
+        torch, dist = self.torch, self.dist
+        ops, recv_bufs = [], {}
+        for q in self.neighbours:
+            if q in self.send_idx:
+                buf = x.index_select(0, self.send_idx[q])
+                if self.staged:
+                    buf = buf.cpu()
+                ops.append(dist.P2POp(dist.isend, buf, q))
+            if q in self.recv_idx:
+                rb = torch.empty(self.recv_idx[q].numel(), dtype=x.dtype, device="cpu" if self.staged else self.device)
+                recv_bufs[q] = rb
+                ops.append(dist.P2POp(dist.irecv, rb, q))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for q, rb in recv_bufs.items():
+            x.index_copy_(0, self.recv_idx[q], rb.to(self.device) if self.staged else rb)
+
+
+class TorchDeviceAllocator:
+    """Installs a torch-backed DEVICE allocator through the reference's own Allocator vtable
+    (alloc.h:19-24) so that device buffers the C layer creates (Krylov work space, matrices)
+    can be handed to torch.distributed as tensors.  Zero-filled like src/alloc.c:23-30."""
+
+    def __init__(self, device):
+        import torch
+        from . import api
+        self.torch, self.device = torch, device
+        self.blocks = {}   # base ptr -> uint8 tensor
+        self.bases = []
+        MALLOC = C.CFUNCTYPE(C.c_void_p, C.c_ssize_t, C.c_void_p)
+        FREE = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p)
+
+        class Allocator(C.Structure):
+            _fields_ = [("malloc", MALLOC), ("free", FREE), ("ctx", C.c_void_p)]
+
+        def _malloc(size, ctx):
+            if size <= 0:
+                return None
+            t = torch.zeros(int(size) + 16, dtype=torch.uint8, device=device)
+            p = t.data_ptr()
+            self.blocks[p] = t
+            self.bases = sorted(self.blocks)
+            return p
+
+        def _free(ptr, size, ctx):
+            if ptr and ptr in self.blocks:
+                del self.blocks[ptr]
+                self.bases = sorted(self.blocks)
+
+        self._m, self._f = MALLOC(_malloc), FREE(_free)
+        L = api.lib()
+        L.GetDefaultAllocator.restype = C.POINTER(Allocator)
+        L.GetDefaultAllocator.argtypes = [C.c_int]
+        a = L.GetDefaultAllocator(1).contents
+        a.malloc, a.free = self._m, self._f
+
+    def tensor(self, ptr, n, dtype=None):
+        """f64 view of n elements at raw device pointer `ptr` (must lie in one of our blocks)."""
+        import bisect
+        torch = self.torch
+        i = bisect.bisect_right(self.bases, ptr) - 1
+        base = self.bases[i]
+        blk = self.blocks[base]
+        off = ptr - base
+        assert 0 <= off and off + 8 * n <= blk.numel(), "pointer outside torch-allocated device memory"
+        return blk[off:off + 8 * n].view(torch.float64)
+
+
+class DistSolverComm:
+    """DflComm callbacks (include/dedflow.h) implemented with torch.distributed."""
+
+    def __init__(self, plan: HaloPlan, alloc: TorchDeviceAllocator, dist):
+        from . import api
+        self.plan, self.alloc, self.dist = plan, alloc, dist
+        self.n_allreduce = 0
+        self.n_halo = 0
+        self.staged = plan.staged
+
+        def _allreduce(ctx, ptr, n):
+            t = self.alloc.tensor(ptr, n)
+            if self.staged:
+                h = t.cpu()
+                dist.all_reduce(h)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t)
+            self.n_allreduce += 1
+
+        def _halo(ctx, ptr):
+            t = self.alloc.tensor(ptr, 4 * plan.n_local)
+            plan.exchange(t)
+            self.n_halo += 1
+
+        self._a, self._h = api.ALLREDUCE_FN(_allreduce), api.HALO_FN(_halo)
+        self.comm = api.DflComm(self._a, self._h, None, plan.n_owned)
+
+    def install(self, ksp):
+        from . import api
+        api.lib().KrylovSetComm(ksp, C.byref(self.comm))

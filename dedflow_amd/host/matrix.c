@@ -149,6 +149,7 @@ static void fs_setup(Matrix* m) {
     for (index_type i = 0; i < n * n; ++i)
         if (fs->mat[i]) MatrixSetup(fs->mat[i]);
     fs->block_mode = fs_is_up_layout(fs);
+    if (fs->owned_rows <= 0 || fs->owned_rows > num_row) fs->owned_rows = num_row;
     if (fs->block_mode) {
         if (!fs->block_val) fs->block_val = (value_type*)CdamMallocDevice((ptrdiff_t)fs->spy1x1->nnz * 16 * SIZE_OF(value_type));
         for (index_type i = 0; i < 2; ++i)
@@ -198,7 +199,8 @@ static void fs_amvpby(Matrix* m, value_type alpha, value_type* x, value_type bet
     MatrixFS* fs = fs_of(m);
     index_type no = fs->n_offset, num_row = fs->spy1x1->num_row, num_col = fs->spy1x1->num_col;
     if (fs->block_mode) { /* scal(4N) + 4 SpMV of matrix.c:471-497 in one launch */
-        dfl_bcsr_spmv(num_row, fs->spy1x1->row_ptr, fs->spy1x1->col_ind, fs->block_val, alpha, x, beta, y, DflStream());
+        dfl_bcsr_spmv_rows(fs->owned_rows, num_row, fs->spy1x1->row_ptr, fs->spy1x1->col_ind, fs->block_val, alpha, x, beta, y,
+                           DflStream());
         return;
     }
     dfl_dscal(no * num_row, beta, y, DflStream());
@@ -262,6 +264,15 @@ Matrix* MatrixCreateTypeFS(index_type n_offset, const index_type* offset, void* 
     m->op->get_diag = fs_get_diag;
     m->op->destroy = fs_destroy;
     return m;
+}
+
+void MatrixFSSetOwnedRows(Matrix* m, index_type n) {
+    if (m && m->type == MAT_TYPE_FS) fs_of(m)->owned_rows = n;
+}
+index_type MatrixFSOwnedRows(Matrix* m) {
+    if (!m || m->type != MAT_TYPE_FS) return m ? MatrixNumRow(m) : 0;
+    MatrixFS* fs = fs_of(m);
+    return fs->owned_rows > 0 ? fs->owned_rows : fs->spy1x1->num_row;
 }
 
 value_type* MatrixFSBlockValues(Matrix* m) {

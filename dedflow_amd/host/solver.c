@@ -145,8 +145,8 @@ static void decomposition_apply(PC* pc, value_type* x, value_type* y) {
     PCDecomposition* d = (PCDecomposition*)pc->data;
     index_type N;
     if (decomposition_is_fused_up(d, &N)) {
-        dfl_pc_jacobi_apply(N, 6 * N, (value_type*)((PCJacobi*)d->pc[0]->data)->diag,
-                            (value_type*)((PCJacobi*)d->pc[1]->data)->diag, x, y, DflStream());
+        dfl_pc_jacobi_apply_rows(MatrixFSOwnedRows((Matrix*)pc->mat), N, 6 * N, (value_type*)((PCJacobi*)d->pc[0]->data)->diag,
+                                 (value_type*)((PCJacobi*)d->pc[1]->data)->diag, x, y, DflStream());
         return;
     }
     for (index_type i = 0; i < d->n_sec; ++i) PCApply(d->pc[i], x + d->offset[i], y + d->offset[i]);
@@ -273,8 +273,9 @@ static void pc_apply_fused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64*
         PCDecomposition* d = (PCDecomposition*)pc->data;
         const f64* d33 = (const f64*)((PCJacobi*)d->pc[0]->data)->diag;
         const f64* d1 = (const f64*)((PCJacobi*)d->pc[1]->data)->diag;
-        if (d_nrm) dfl_pc_jacobi_apply_scaled(N, na, d33, d1, w, d_nrm, w, z, DflStream());
-        else dfl_pc_jacobi_apply(N, na, d33, d1, w, z, DflStream());
+        const index_type nrows = MatrixFSOwnedRows((Matrix*)pc->mat);
+        if (d_nrm) dfl_pc_jacobi_apply_scaled_rows(nrows, N, na, d33, d1, w, d_nrm, w, z, DflStream());
+        else dfl_pc_jacobi_apply_rows(nrows, N, na, d33, d1, w, z, DflStream());
         return;
     }
     if (d_nrm) dfl_dscal_inv_dev(na, d_nrm, w, DflStream());

@@ -241,6 +241,7 @@ struct MatrixFS {
     /* ext */
     b32 block_mode;        /* the (u,p) 2x2 layout of src/main.c:374-391 was recognised */
     value_type* block_val; /* [nnz1][16] device, 4x4 blocks over spy1x1 */
+    index_type owned_rows; /* node rows this rank owns (== spy1x1->num_row on one GPU): SpMV / PC run on these only */
 };
 Matrix* MatrixCreateTypeCSR(const CSRAttr* attr, void*);
 Matrix* MatrixCreateTypeFS(index_type n_offset, const index_type* offset, void*);
@@ -262,6 +263,12 @@ value_type* MatrixFSBlockValues(Matrix* matrix); /* NULL unless block mode */
 /* fills the four sub-matrices' `val` arrays (reference layout) from the block storage, allocating them on first use */
 void MatrixFSExportSubmatrices(Matrix* matrix);
 void MatrixFSImportSubmatrices(Matrix* matrix);
+/* element-partitioned runs: local nodes are numbered owned-first; rows >= n are ghost rows */
+void MatrixFSSetOwnedRows(Matrix* matrix, index_type n);
+index_type MatrixFSOwnedRows(Matrix* matrix);
+/* recursive coordinate bisection of tet centroids into num_part parts (the reference's METIS
+ * wrapper, src/partition.c:16-77, is dead code and METIS is unavailable): epart[T] on the host */
+void DflPartitionRCB(index_type num_tet, const index_type* ien, const f64* xg, index_type num_part, index_type* epart);
 
 /* ---- vectors (vec.h) --------------------------------------------------------------- */
 void VecAXPY(value_type a, const value_type* x, value_type* y, index_type n);

@@ -84,6 +84,16 @@ void GMRESResidualUpdatePrivate(dfl_value* beta, dfl_value* gv); /* same symbol 
  *      y[0:4N] = alpha * A * x[0:4N] + beta * y[0:4N] */
 void dfl_bcsr_spmv(dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val, dfl_value alpha,
                    const dfl_value* x, dfl_value beta, dfl_value* y, void* stream);
+/* element-partitioned runs: only the first `nrows` node rows (the nodes this rank owns) are
+ * computed; x / y keep the local layout with N = owned + ghost nodes */
+void dfl_bcsr_spmv_rows(dfl_index nrows, dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val,
+                        dfl_value alpha, const dfl_value* x, dfl_value beta, dfl_value* y, void* stream);
+void dfl_pc_jacobi_setup_rows(dfl_index nrows, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val,
+                              dfl_value* dinv33, dfl_value* dinv1, void* stream);
+void dfl_pc_jacobi_apply_rows(dfl_index nrows, dfl_index N, dfl_index n, const dfl_value* dinv33, const dfl_value* dinv1,
+                              const dfl_value* x, dfl_value* y, void* stream);
+void dfl_pc_jacobi_apply_scaled_rows(dfl_index nrows, dfl_index N, dfl_index n, const dfl_value* dinv33, const dfl_value* dinv1,
+                                     const dfl_value* w, const dfl_value* d_nrm, dfl_value* q_out, dfl_value* y, void* stream);
 /* scalar CSR SpMV for the reference-layout sub-matrices (cusparseSpMV, matrix.c:151-162) */
 void dfl_csr_spmv(dfl_index nrow, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val, dfl_value alpha,
                   const dfl_value* x, dfl_value beta, dfl_value* y, void* stream);

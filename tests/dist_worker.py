@@ -1,0 +1,175 @@
+"""Worker for the multi-rank tests (launched by torch.distributed.run, gloo backend).
+
+mode "cpu": the distributed ALGORITHM (RCB partition, owner-first numbering, halo plan,
+            owned-rows SpMV, all-reduced CGS) with the CPU oracle as local compute --
+            runs in the GPU-less container.
+mode "gpu": the PRODUCT path -- C host GMRES + HIP kernels per rank with the DflComm
+            callbacks on torch.distributed -- several ranks sharing cuda:0 (gloo with host
+            staging; RCCL refuses two ranks on one device).
+Both compare against the global single-domain oracle solve.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def global_reference(mesh, its):
+    from dedflow_amd.meshgen import synthetic_fields
+    from oracle import orc
+    S = orc.System(mesh)
+    wg, dwg = synthetic_fields(mesh)
+    F, vals = S.assemble_system(wg, dwg, True, True)
+    x, hist, r0, it = S.gmres(vals, F, maxit=its, atol=0.0, rtol=0.0)
+    return S, wg, dwg, F, vals, x, hist, r0
+
+
+def run_cpu(rank, world, M, its):
+    import torch
+    import torch.distributed as dist
+    from dedflow_amd import dist as D
+    from dedflow_amd.meshgen import kuhn_cube
+    from oracle import orc
+    mesh = kuhn_cube(M, jitter=0.2)
+    Sg, wg, dwg, Fg, valsg, xg_, histg, r0g = global_reference(mesh, its)
+    epart = D.partition_rcb(mesh, world)
+    assert np.bincount(epart, minlength=world).min() > 0
+    owner = D.node_owner(mesh, epart, world)
+    lm = D.build_local(mesh, epart, owner, rank, world)
+    n, no, Ng = lm.l2g_node.size, lm.n_owned, mesh.num_node
+    # ownership is a partition of the nodes
+    cnt = torch.tensor([float(no)], dtype=torch.float64)
+    dist.all_reduce(cnt)
+    assert int(cnt.item()) == Ng
+    S = orc.System(lm.mesh)
+    F, vals = S.assemble_system(D.localize_vector(wg, lm, Ng), D.localize_vector(dwg, lm, Ng), True, True)
+    plan = D.HaloPlan(lm, dist, torch.device("cpu"), False)
+    own4 = np.concatenate([np.arange(3 * no), 3 * n + np.arange(no)])
+    ghost4 = np.concatenate([np.arange(3 * no, 3 * n), 3 * n + np.arange(no, n)])
+    gidx4 = np.concatenate([(3 * lm.l2g_node[:no, None] + np.arange(3)).reshape(-1), 3 * Ng + lm.l2g_node[:no]])
+
+    # owned rows of the locally assembled F / matrix are complete (zero assembly communication)
+    assert np.abs(F[own4] - Fg[gidx4]).max() <= 1e-10 * np.abs(Fg).max()
+
+    def halo(v):
+        t = torch.from_numpy(v[:4 * n])
+        plan.exchange(t)
+
+    def spmv_owned(x):
+        y = S.matvec(vals, x)
+        y[ghost4] = 0.0
+        return y
+
+    xr = np.random.default_rng(3).normal(size=6 * Ng)
+    xl = D.localize_vector(xr, lm, Ng)
+    xl[ghost4] = 1e30  # must be overwritten by the exchange
+    halo(xl)
+    assert np.array_equal(xl[ghost4], D.localize_vector(xr, lm, Ng)[ghost4])
+    yl = spmv_owned(xl)
+    yg = Sg.matvec(valsg, xr)
+    assert np.abs(yl[own4] - yg[gidx4]).max() <= 1e-10 * np.abs(yg).max()
+
+    # distributed right-preconditioned GMRES (mirror of dedflow_amd/host/solver.c)
+    d33, d1 = S.pc_setup(vals)
+
+    def pc(v):
+        with np.errstate(all="ignore"):
+            z = S.pc_apply(d33, d1, v)
+        z[ghost4] = 0.0
+        z[4 * n:] = 0.0
+        return z
+
+    def allsum(a):
+        t = torch.from_numpy(np.atleast_1d(np.asarray(a, dtype=np.float64)).copy())
+        dist.all_reduce(t)
+        return t.numpy()
+
+    b = F.copy()
+    b[ghost4] = 0.0
+    Q = np.zeros((its + 1, 6 * n))
+    H = np.zeros((its + 1, its))
+    r0 = np.sqrt(allsum(b @ b)[0])
+    Q[0] = b / r0
+    beta = np.zeros(its + 1)
+    beta[0] = r0
+    gv = np.zeros((its, 2))
+    hist = []
+    for k in range(its):
+        z = pc(Q[k])
+        halo(z)
+        w = spmv_owned(z)
+        h = allsum(Q[:k + 1] @ w)
+        w = w - h @ Q[:k + 1]
+        nr = np.sqrt(allsum(w @ w)[0])
+        H[:k + 1, k] = h
+        H[k + 1, k] = nr
+        Q[k + 1] = w / nr
+        for i in range(k):
+            c, s = gv[i]
+            a, bb = H[i, k], H[i + 1, k]
+            H[i, k], H[i + 1, k] = c * a + s * bb, c * bb - s * a
+        r = np.hypot(H[k, k], H[k + 1, k])
+        c, s = H[k, k] / r, H[k + 1, k] / r
+        gv[k] = (c, s)
+        H[k, k], H[k + 1, k] = r, 0.0
+        beta[k + 1] = -s * beta[k]
+        beta[k] = c * beta[k]
+        hist.append(abs(beta[k + 1]))
+    hist = np.array(hist)
+    assert abs(r0 - r0g) <= 1e-12 * r0g
+    assert np.abs(hist - histg).max() <= 1e-8 * r0g, np.abs(hist - histg).max() / r0g
+    y = np.linalg.solve(np.triu(H[:its, :its]), beta[:its])
+    x = pc(y @ Q[:its])
+    assert np.abs(x[own4] - xg_[gidx4]).max() <= 1e-6 * np.abs(xg_).max()
+    if rank == 0:
+        print("DIST_CPU_OK", world, no, n, len(plan.neighbours))
+
+
+def run_gpu(rank, world, M, its):
+    import torch
+    import torch.distributed as dist
+    from dedflow_amd import api, dist_bench
+    from dedflow_amd import dist as D
+    from dedflow_amd.meshgen import kuhn_cube
+    mesh = kuhn_cube(M, jitter=0.2)
+    Sg, wg, dwg, Fg, valsg, xg_, histg, r0g = global_reference(mesh, its)
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    lm, alloc, P, plan, comm = dist_bench.setup_rank(mesh, rank, world, device, dist, its, True)
+    Ng, n, no = mesh.num_node, P.N, lm.n_owned
+    wg_t, wg_p = dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(wg, lm, Ng))
+    dwg_t, dwg_p = dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(dwg, lm, Ng))
+    F_t, F_p = dist_bench.device_vector(alloc, torch, device, 6 * n)
+    x_t, x_p = dist_bench.device_vector(alloc, torch, device, 6 * n)
+    Pp = dist_bench._Ptr
+    P.assemble_system(Pp(wg_p), Pp(dwg_p), Pp(F_p), want_J=False)
+    P.assemble_system(Pp(wg_p), Pp(dwg_p), None, want_J=True)
+    F_t[3 * no:3 * n].zero_()
+    F_t[3 * n + no:4 * n].zero_()
+    it, r0, hist, _ = P.solve(Pp(x_p), Pp(F_p))
+    torch.cuda.synchronize()
+    own4 = np.concatenate([np.arange(3 * no), 3 * n + np.arange(no)])
+    gidx4 = np.concatenate([(3 * lm.l2g_node[:no, None] + np.arange(3)).reshape(-1), 3 * Ng + lm.l2g_node[:no]])
+    Fl = F_t.cpu().numpy()
+    assert np.abs(Fl[own4] - Fg[gidx4]).max() <= 1e-10 * np.abs(Fg).max()
+    assert it == its and abs(r0 - r0g) <= 1e-12 * r0g
+    assert np.abs(hist - histg).max() <= 1e-8 * r0g, np.abs(hist - histg).max() / r0g
+    xl = x_t.cpu().numpy()
+    assert np.abs(xl[own4] - xg_[gidx4]).max() <= 1e-6 * np.abs(xg_).max()
+    dist.barrier()
+    if rank == 0:
+        print("DIST_GPU_OK", world, comm.n_allreduce, comm.n_halo)
+    P.close()
+
+
+if __name__ == "__main__":
+    import torch.distributed as dist
+    mode, M, its = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    (run_cpu if mode == "cpu" else run_gpu)(rank, world, M, its)
+    dist.barrier()
+    dist.destroy_process_group()

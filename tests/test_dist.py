@@ -1,0 +1,44 @@
+"""Multi-rank tests (torch.distributed.run, gloo).  CPU leg: the distributed algorithm with
+the oracle as local compute (world_size 2 and 3).  GPU leg: the product path -- C GMRES +
+HIP kernels + DflComm callbacks -- with 2 and 3 ranks sharing the one GPU of the box."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(mode, world, M, its, timeout=600):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(M), str(its)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_algorithm_cpu_gloo(world, oracle_lib):
+    subprocess.check_call(["make", "-s", "-j8", "-C", ROOT])
+    out = _launch("cpu", world, 6, 25)
+    assert "DIST_CPU_OK" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_product_path_gpu_gloo(world, oracle_lib):
+    out = _launch("gpu", world, 8, 30)
+    assert "DIST_GPU_OK" in out
