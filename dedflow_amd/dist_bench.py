@@ -53,6 +53,8 @@ def run(args, rank, world, local_rank):
     from .meshgen import kuhn_cube, synthetic_fields
 
     backend = os.environ.get("DFL_BACKEND", "nccl")
+    if "DFL_FORCE_DEVICE" in os.environ:  # rehearsal of several ranks on one GPU (gloo only)
+        local_rank = int(os.environ["DFL_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
