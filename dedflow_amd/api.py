@@ -215,6 +215,7 @@ def _declare(L):
     i32, f64 = C.c_int32, C.c_double
     f("Init", None, [C.c_int, vp]); f("Finalize", None, [])
     f("DflStream", vp, []); f("DflSetStream", None, [vp]); f("DflSetQuiet", None, [i32])
+    f("DflSetAssemblySchedule", None, [C.c_int])
     f("Mesh3DCreate", C.POINTER(Mesh3D), [i32, i32, i32, i32]); f("Mesh3DDestroy", None, [C.POINTER(Mesh3D)])
     f("Mesh3DUpdateDevice", None, [C.POINTER(Mesh3D)]); f("Mesh3DGenerateColorBatch", None, [C.POINTER(Mesh3D)])
     f("Mesh3DSetBound", None, [C.POINTER(Mesh3D), i32, vp, vp, vp, vp, vp])
@@ -259,10 +260,11 @@ REFERENCE_BCS = [(0, (1, 1, 1)), (2, (0, 1, 0)), (3, (0, 0, 1)), (4, (0, 0, 0))]
 class Problem:
     """The reference driver's setup sequence (src/main.c:362-477) through the C API."""
 
-    def __init__(self, mesh, maxit=120, atol=1e-12, rtol=1e-4, quiet=True, bcs=REFERENCE_BCS, color=True):
+    def __init__(self, mesh, maxit=120, atol=1e-12, rtol=1e-4, quiet=True, bcs=REFERENCE_BCS, color=True, schedule=1):
         L = lib()
         L.Init(0, None)
         L.DflSetQuiet(1 if quiet else 0)
+        L.DflSetAssemblySchedule(int(schedule))
         self.mesh_np = mesh
         self.N, self.T = mesh.num_node, mesh.num_tet
         self.mesh = L.Mesh3DCreate(self.N, self.T, 0, 0)

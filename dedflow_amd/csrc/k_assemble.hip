@@ -260,10 +260,13 @@ constexpr int RBLK = 256;
 constexpr int REPB = RBLK / 4;
 constexpr int NV = 14;  // x(3) u(3) phi T du(3) p dphi dT per node
 
-__device__ __forceinline__ double quad_sum(double v) {
-    v += __shfl_xor(v, 1, WAVE);
-    v += __shfl_xor(v, 2, WAVE);
-    return v;
+// value of lane (l ^ 1) [CTRL 0xB1] or (l ^ 2) [CTRL 0x4E] inside each quad: DPP quad_perm, no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
 }
 
 __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict__ ien_b, I N, const T* __restrict__ xg,
@@ -391,39 +394,45 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
     const double wq = GW * detJ;
     const double bp = qd[4] + uadv[0] * grad[3 * 4 + 0] + uadv[1] * grad[3 * 4 + 1] + uadv[2] * grad[3 * 4 + 2];
     const double btc = kRHO * kCP * (qd[5] + uadv[0] * grad[3 * 5 + 0] + uadv[1] * grad[3 * 5 + 1] + uadv[2] * grad[3 * 5 + 2]);
-    double mine[6] = {0, 0, 0, 0, 0, 0};
+    // Each lane holds one quadrature point's contribution to all 4 rows; lane `a` needs row a
+    // summed over the 4 points: reduce-scatter inside the quad with two DPP exchanges
+    // (xor 2 keeps the row pair of the own half, xor 1 keeps the own row).
+    (void)wq;
+    double mine[6];
+    const bool hi2 = (a >> 1) != 0, hi1 = (a & 1) != 0;
 #pragma unroll
-    for (int aa = 0; aa < 4; ++aa) {
-        double c[6];
+    for (int j = 0; j < 6; ++j) {
+        double c[4];
 #pragma unroll
-        for (int ii = 0; ii < 3; ++ii) {
-            double bm = 0.0;
-            bm += shl(aa, iq) * tmp0[ii];
-            bm += shg[aa * 3 + 0] * tmp1[ii * 3 + 0];
-            bm += shg[aa * 3 + 1] * tmp1[ii * 3 + 1];
-            bm += shg[aa * 3 + 2] * tmp1[ii * 3 + 2];
-            c[ii] = bm * GW * detJ;
+        for (int aa = 0; aa < 4; ++aa) {
+            if (j < 3) {
+                double bm = 0.0;
+                bm += shl(aa, iq) * tmp0[j];
+                bm += shg[aa * 3 + 0] * tmp1[j * 3 + 0];
+                bm += shg[aa * 3 + 1] * tmp1[j * 3 + 1];
+                bm += shg[aa * 3 + 2] * tmp1[j * 3 + 2];
+                c[aa] = bm * GW * detJ;
+            } else if (j == 3) {
+                double bc = 0.0;
+                bc += shl(aa, iq) * divu;
+                bc += tau[0] * rLi[0] * shg[aa * 3 + 0];
+                bc += tau[0] * rLi[1] * shg[aa * 3 + 1];
+                bc += tau[0] * rLi[2] * shg[aa * 3 + 2];
+                c[aa] = bc * GW * detJ;
+            } else if (j == 4) {
+                c[aa] = bp * (shl(aa, iq) + tau[2] * shconv[aa]) * GW * detJ;
+            } else {
+                double bt = btc * (shl(aa, iq) + kRHO * kCP * tau[3] * shconv[aa]);
+                bt += kKAPPA * (grad[3 * 5 + 0] * shg[aa * 3 + 0] + grad[3 * 5 + 1] * shg[aa * 3 + 1] + grad[3 * 5 + 2] * shg[aa * 3 + 2]);
+                c[aa] = bt * GW * detJ;
+            }
         }
-        {
-            double bc = 0.0;
-            bc += shl(aa, iq) * divu;
-            bc += tau[0] * rLi[0] * shg[aa * 3 + 0];
-            bc += tau[0] * rLi[1] * shg[aa * 3 + 1];
-            bc += tau[0] * rLi[2] * shg[aa * 3 + 2];
-            c[3] = bc * GW * detJ;
-        }
-        c[4] = bp * (shl(aa, iq) + tau[2] * shconv[aa]) * GW * detJ;
-        {
-            double bt = btc * (shl(aa, iq) + kRHO * kCP * tau[3] * shconv[aa]);
-            bt += kKAPPA * (grad[3 * 5 + 0] * shg[aa * 3 + 0] + grad[3 * 5 + 1] * shg[aa * 3 + 1] + grad[3 * 5 + 2] * shg[aa * 3 + 2]);
-            c[5] = bt * GW * detJ;
-        }
-        (void)wq;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const double tot = quad_sum(c[j]);  // sum over the 4 quadrature points
-            if (aa == a) mine[j] = tot;
-        }
+        const double k0 = hi2 ? c[2] : c[0], k1 = hi2 ? c[3] : c[1];
+        const double s0 = hi2 ? c[0] : c[2], s1 = hi2 ? c[1] : c[3];
+        const double r0 = k0 + dpp_quad<0x4E>(s0);
+        const double r1 = k1 + dpp_quad<0x4E>(s1);
+        const double keep = hi1 ? r1 : r0, send = hi1 ? r0 : r1;
+        mine[j] = keep + dpp_quad<0xB1>(send);
     }
     // ElemRHSLocal2Global: non-atomic, race-free inside a color
     F[3 * node + 0] += mine[0];

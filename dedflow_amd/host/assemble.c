@@ -46,10 +46,12 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
         spy = block_pattern(J, &val);
         ensure_nzmap(mesh, spy);
     }
-    for (index_type b = 0; b < mesh->num_batch; ++b) {
-        const index_type off = mesh->batch_offset[b];
-        const index_type bsz = mesh->batch_offset[b + 1] - off;
-        if (bsz == 0) break; /* assemble.cu:1565-1567 */
+    /* one launch per class of the execution schedule (mesh.c: the reference's color batches in
+       mode 0, the compact re-coloring otherwise) */
+    for (index_type b = 0; b < x->sched_num; ++b) {
+        const index_type off = x->sched_offset[b];
+        const index_type bsz = x->sched_offset[b + 1] - off;
+        if (bsz == 0) continue;
         const index_type* ien_b = x->ien_b + (size_t)off * 4;
         if (F) DFL_TIMED(DFL_TAG_ASM_RHS, dfl_assemble_tet_rhs(bsz, ien_b, N, dev->xg, wgalpha_dptr, dwgalpha_dptr, F, s));
         if (J) DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, dev->xg, wgalpha_dptr, val, s));
@@ -70,7 +72,7 @@ void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, 
     const index_type* f2e = Mesh3DBoundF2E(mesh, group);
     const index_type* forn = Mesh3DBoundFORN(mesh, group);
     int slot = DflProfileBegin(DFL_TAG_FACE);
-    for (index_type c = 0; c < mesh->num_color; ++c) { /* one launch per parent color: race-free, color order */
+    for (index_type c = 0; c < x->face_num_class; ++c) { /* one launch per conflict-free face class */
         index_type lo = x->face_color_offset[c], nf = x->face_color_offset[c + 1] - lo;
         if (!nf) continue;
         dfl_assemble_face(nf, x->face_list + lo, f2e, forn, dev->ien, N, dev->xg, wgalpha_dptr, dwgalpha_dptr, F,

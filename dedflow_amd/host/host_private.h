@@ -4,16 +4,20 @@
 #include "dedflow.h"
 
 typedef struct MeshExt {
-    index_type* ien_b;             /* device [T][4], elements in batch (color-major) order */
+    index_type* ien_b;             /* device [T][4], elements in execution-schedule order */
+    index_type sched_num;          /* number of conflict-free launches of the execution schedule */
+    index_type* sched_offset;      /* host [sched_num+1] */
     index_type* nzmap_b;           /* device [T][16], (elem,a,b) -> nodal nonzero, batch order */
     const CSRAttr* nzmap_attr;     /* pattern the map was built for */
     index_type face_group;         /* boundary group the face list below belongs to (-1: none) */
-    index_type* face_list;         /* device: faces of that group ordered by parent color */
-    index_type* face_color_offset; /* host [num_color+1] */
+    index_type* face_list;         /* device: faces of that group ordered by class */
+    index_type* face_color_offset; /* host [face_num_class+1] */
+    index_type face_num_class;     /* conflict-free face classes (greedy node coloring of the group's faces) */
     index_type* h_f2e;             /* host copy of bound_f2e */
 } MeshExt;
 
 void DflMeshPrepareFaces(Mesh3D* mesh, index_type group);
+int DflAssemblyScheduleMode(void);
 b32 DflQuiet(void);
 
 /* profiling tags (runtime.c) */

@@ -93,6 +93,7 @@ void Mesh3DDestroy(Mesh3D* m) {
         CdamFreeDevice(x->nzmap_b, 0);
         CdamFreeDevice(x->face_list, 0);
         if (x->face_color_offset) CdamFreeHost(x->face_color_offset, 0);
+        if (x->sched_offset) CdamFreeHost(x->sched_offset, 0);
         if (x->h_f2e) CdamFreeHost(x->h_f2e, 0);
         CdamFreeHost(x, SIZE_OF(MeshExt));
     }
@@ -132,6 +133,61 @@ void Mesh3DColor(Mesh3D* mesh) {
     mesh->num_color = GetMaxColor(mesh->color, T) + 1;
 }
 
+static int g_sched_mode = 1;
+/* 0: launches follow the reference's JPL color batches one to one (same summation order as
+ *    the reference inside every matrix / RHS entry);
+ * 1: (default) compact schedule below.  Results differ from mode 0 by summation order only. */
+void DflSetAssemblySchedule(int mode) { g_sched_mode = mode; }
+int DflAssemblyScheduleMode(void) { return g_sched_mode; }
+
+/* JPL colors one independent set of local maxima per round, i.e. ~140 colors of ~T/140 tets
+ * for a tet mesh whose conflict graph needs ~30.  A 77k-tet launch is 4.4 waves per SIMD for
+ * the 4-lane RHS kernel: latency-bound.  The coloring stays exactly the reference's
+ * (mesh->color / batch_offset / batch_ind are bit-identical and remain the public result);
+ * what the assembly kernels EXECUTE is a second, balanced greedy coloring with ~4x fewer and
+ * ~4x larger conflict-free launches.  First-fit over node bit masks, least-loaded free class. */
+static void build_compact_schedule(Mesh3D* mesh, MeshExt* x) {
+    const index_type T = mesh->num_tet, N = mesh->num_node;
+    const index_type* ien = mesh->host->ien;
+    u64* node_mask = (u64*)CdamMallocHost((ptrdiff_t)N * (ptrdiff_t)sizeof(u64));
+    memset(node_mask, 0, (size_t)N * sizeof(u64));
+    u8* cls = (u8*)CdamMallocHost((ptrdiff_t)T);
+    index_type count[64];
+    memset(count, 0, sizeof count);
+    int nopen = 1;
+    for (index_type e = 0; e < T; ++e) {
+        const index_type* nd = ien + (size_t)e * 4;
+        const u64 used = node_mask[nd[0]] | node_mask[nd[1]] | node_mask[nd[2]] | node_mask[nd[3]];
+        int best = -1;
+        for (int c = 0; c < nopen; ++c)
+            if (!((used >> c) & 1ULL) && (best < 0 || count[c] < count[best])) best = c;
+        if (best < 0) {
+            ASSERT(nopen < 64 && "compact schedule needs more than 64 classes");
+            best = nopen++;
+        }
+        cls[e] = (u8)best;
+        count[best]++;
+        const u64 bit = 1ULL << best;
+        node_mask[nd[0]] |= bit; node_mask[nd[1]] |= bit; node_mask[nd[2]] |= bit; node_mask[nd[3]] |= bit;
+    }
+    x->sched_num = nopen;
+    x->sched_offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (nopen + 1));
+    x->sched_offset[0] = 0;
+    for (int c = 0; c < nopen; ++c) x->sched_offset[c + 1] = x->sched_offset[c] + count[c];
+    index_type* ind = (index_type*)CdamMallocHost((ptrdiff_t)T * SIZE_OF(index_type));
+    index_type cur[64];
+    memcpy(cur, x->sched_offset, sizeof(index_type) * (size_t)nopen);
+    for (index_type e = 0; e < T; ++e) ind[cur[cls[e]]++] = e; /* ascending element id inside a class */
+    index_type* d_ind = (index_type*)CdamMallocDevice((ptrdiff_t)T * SIZE_OF(index_type));
+    HIPGUARD(hipMemcpy(d_ind, ind, sizeof(index_type) * (size_t)T, H2D));
+    dfl_gather_ien(T, mesh->device->ien, d_ind, x->ien_b, DflStream());
+    HIPGUARD(hipStreamSynchronize(DflStream()));
+    CdamFreeDevice(d_ind, 0);
+    CdamFreeHost(ind, 0);
+    CdamFreeHost(cls, 0);
+    CdamFreeHost(node_mask, 0);
+}
+
 /* Mesh3DGenerateColorBatch, src/Mesh.c:165-206.  The per-color count + copy_if passes
  * are one stable sort by color; additionally the connectivity is re-laid out in batch
  * order so that each color's launch streams its ien (and nz map) contiguously. */
@@ -146,7 +202,16 @@ void Mesh3DGenerateColorBatch(Mesh3D* mesh) {
     mesh->batch_ind = (index_type*)CdamMallocDevice((ptrdiff_t)T * SIZE_OF(index_type));
     dfl_color_batches(mesh->color, T, nc, mesh->batch_offset, mesh->batch_ind);
     x->ien_b = (index_type*)CdamMallocDevice((ptrdiff_t)T * 4 * SIZE_OF(index_type));
-    dfl_gather_ien(T, mesh->device->ien, mesh->batch_ind, x->ien_b, DflStream());
+    if (x->sched_offset) CdamFreeHost(x->sched_offset, 0);
+    if (DflAssemblyScheduleMode() == 0) {
+        /* execution schedule == the reference's JPL color batches */
+        x->sched_num = nc;
+        x->sched_offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (nc + 1));
+        memcpy(x->sched_offset, mesh->batch_offset, sizeof(index_type) * (size_t)(nc + 1));
+        dfl_gather_ien(T, mesh->device->ien, mesh->batch_ind, x->ien_b, DflStream());
+    } else {
+        build_compact_schedule(mesh, x);
+    }
     HIPGUARD(hipStreamSynchronize(DflStream()));
 }
 
@@ -155,26 +220,45 @@ void Mesh3DGenerateColorBatch(Mesh3D* mesh) {
 void DflMeshPrepareFaces(Mesh3D* mesh, index_type group) {
     MeshExt* x = (MeshExt*)mesh->ext;
     if (x->face_group == group) return;
-    index_type nf = Mesh3DBoundNumElem(mesh, group), nc = mesh->num_color, T = mesh->num_tet;
+    /* The reference scatters the faces once per ELEMENT color (141 masked passes at 10M tets for
+     * 28k faces).  Faces only conflict through the 4 nodes of their parent tets, so they are
+     * greedily colored here into a handful of conflict-free classes (<= 64) -> one launch per class.
+     * Deterministic; the order in which a node receives its face contributions is class order
+     * instead of parent-color order (rounding-level difference only). */
+    index_type nf = Mesh3DBoundNumElem(mesh, group), N = mesh->num_node;
     index_type lo = mesh->bound_elem_offset[group];
+    const index_type* h_ien = mesh->host->ien;
     CdamFreeDevice(x->face_list, 0);
     if (x->face_color_offset) CdamFreeHost(x->face_color_offset, 0);
-    x->face_color_offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (nc + 1));
-    index_type* h_color = (index_type*)CdamMallocHost((ptrdiff_t)T * SIZE_OF(index_type));
-    HIPGUARD(hipMemcpy(h_color, mesh->color, sizeof(index_type) * (size_t)T, D2H));
+    x->face_color_offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * 66);
+    memset(x->face_color_offset, 0, sizeof(index_type) * 66);
+    u64* node_mask = (u64*)CdamMallocHost((ptrdiff_t)N * (ptrdiff_t)sizeof(u64));
+    memset(node_mask, 0, (size_t)N * sizeof(u64));
+    u8* cls = (u8*)CdamMallocHost((ptrdiff_t)(nf > 0 ? nf : 1));
+    index_type ncls = 0;
+    for (index_type f = 0; f < nf; ++f) {
+        const index_type* nd = h_ien + (size_t)x->h_f2e[lo + f] * 4;
+        u64 used = node_mask[nd[0]] | node_mask[nd[1]] | node_mask[nd[2]] | node_mask[nd[3]];
+        int c = 0;
+        while (c < 63 && ((used >> c) & 1ULL)) ++c;
+        ASSERT(!((used >> c) & 1ULL) && "more than 64 face classes");
+        cls[f] = (u8)c;
+        for (int a = 0; a < 4; ++a) node_mask[nd[a]] |= (1ULL << c);
+        if (c + 1 > ncls) ncls = c + 1;
+        x->face_color_offset[c + 1]++;
+    }
+    for (index_type c = 0; c < ncls; ++c) x->face_color_offset[c + 1] += x->face_color_offset[c];
     index_type* list = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (ptrdiff_t)(nf > 0 ? nf : 1));
-    memset(x->face_color_offset, 0, sizeof(index_type) * (size_t)(nc + 1));
-    for (index_type f = 0; f < nf; ++f) x->face_color_offset[h_color[x->h_f2e[lo + f]] + 1]++;
-    for (index_type c = 0; c < nc; ++c) x->face_color_offset[c + 1] += x->face_color_offset[c];
-    index_type* cur = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (nc + 1));
-    memcpy(cur, x->face_color_offset, sizeof(index_type) * (size_t)(nc + 1));
-    for (index_type f = 0; f < nf; ++f) list[cur[h_color[x->h_f2e[lo + f]]]++] = f; /* stable: ascending face id per color */
+    index_type cur[65];
+    memcpy(cur, x->face_color_offset, sizeof(index_type) * 65);
+    for (index_type f = 0; f < nf; ++f) list[cur[cls[f]]++] = f; /* stable: ascending face id per class */
     x->face_list = (index_type*)CdamMallocDevice(SIZE_OF(index_type) * (ptrdiff_t)(nf > 0 ? nf : 1));
     HIPGUARD(hipMemcpy(x->face_list, list, sizeof(index_type) * (size_t)nf, H2D));
     x->face_group = group;
-    CdamFreeHost(cur, 0);
+    x->face_num_class = ncls;
     CdamFreeHost(list, 0);
-    CdamFreeHost(h_color, 0);
+    CdamFreeHost(cls, 0);
+    CdamFreeHost(node_mask, 0);
 }
 
 /* ---- csr.h ------------------------------------------------------------------------ */

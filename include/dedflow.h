@@ -359,6 +359,11 @@ void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, 
 /* the caller of the hot path, src/main.c:31-75 (static there) */
 void AssembleSystem(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, Dirichlet** bcs, index_type nbc);
 void DflSetQuiet(b32 quiet); /* suppress the reference's stdout chatter ("Assemble: F J", timers) */
+/* which conflict-free launches the assembly kernels execute (set BEFORE Mesh3DGenerateColorBatch):
+ *   0  the reference's JPL color batches, one launch per color (reference summation order)
+ *   1  (default) compact balanced re-coloring, ~4x fewer / larger launches; mesh->color,
+ *      batch_offset and batch_ind are the reference's JPL result in both modes */
+void DflSetAssemblySchedule(int mode);
 
 /* ---- arrays / particles (Array.h, Particle.h) ------------------------------------------ */
 typedef struct Array {

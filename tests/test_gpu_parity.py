@@ -259,6 +259,37 @@ def test_golden_fixtures(name, api):
         P.close()
 
 
+def test_reference_color_schedule_matches_compact_schedule(api, oracle_lib):
+    """Schedule 0 launches the reference's JPL color batches one to one (reference summation
+    order); schedule 1 (default) executes a compact re-coloring.  Same coloring artefacts, same
+    values up to summation order."""
+    m = kuhn_cube(8, jitter=0.2)
+    S = oracle_lib.System(m)
+    wg, dwg = synthetic_fields(m)
+    F, vals = S.assemble_system(wg, dwg, True, True)
+    out = []
+    for mode in (0, 1):
+        P = api.Problem(m, schedule=mode)
+        try:
+            assert np.array_equal(P.color(), S.color) and np.array_equal(P.batch_ind(), S.batch_ind)
+            wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+            F_d = api.DeviceArray(6 * S.N)
+            P.assemble_system(wg_d, dwg_d, F_d, want_J=False)
+            P.assemble_system(wg_d, dwg_d, None, want_J=True)
+            api.sync()
+            out.append((F_d.numpy(), P.export_values()))
+        finally:
+            P.close()
+    for Fg, vg in out:
+        ok, err = close(Fg, F)
+        assert ok, err
+        for g, o in zip(vg, vals):
+            ok, err = close(g, o)
+            assert ok, err
+    # the two schedules agree to rounding, far inside the parity bar
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-13 * np.abs(F).max()
+
+
 def test_single_tet_all_faces(api, oracle_lib):
     """DBG_TET-like case (src/main.c:357-361): one element, face assembly on a chosen group."""
     m = single_tet()
