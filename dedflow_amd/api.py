@@ -199,6 +199,46 @@ class Dirichlet(C.Structure):
     # followed by BCType bctype[shape]
 
 
+class Array(C.Structure):
+    _fields_ = [("is_host", C.c_int32), ("len", C.c_int32), ("data", vp)]
+
+
+class ParticleContext(C.Structure):
+    _fields_ = [("num_particle", C.c_int32), ("num_pointwise_dof", C.c_int32), ("h_arr", C.POINTER(Array) * 3),
+                ("d_arr", C.POINTER(Array) * 3), ("buff", C.c_double * 2), ("ext", vp)]
+
+
+class Particles:
+    """ParticleContext (src/Particle.h) + the build-defined contact sweep."""
+
+    def __init__(self, coord, vel, radius, mass=1.0, kn=1.0e4, gamma_n=1.0, dt=1.0e-4):
+        L = lib()
+        L.Init(0, None)
+        P = coord.size // 3
+        self.P = P
+        self.ctx = L.ParticleContextCreate(P)
+        c = self.ctx.contents
+        c.buff[0], c.buff[1] = mass, radius
+        C.memmove(c.h_arr[0].contents.data, np.ascontiguousarray(coord).ctypes.data, 24 * P)
+        C.memmove(c.h_arr[1].contents.data, np.ascontiguousarray(vel).ctypes.data, 24 * P)
+        L.ParticleContextUpdateDevice(self.ctx)
+        L.ParticleContextSetContactModel(self.ctx, kn, gamma_n, dt)
+
+    def compute_forces(self):
+        lib().ParticleContextComputeForces(self.ctx)
+
+    def update(self):
+        lib().ParticleContextUpdate(self.ctx)
+
+    def arrays(self):
+        """(coord, vel, acc) copied back from the device"""
+        c = self.ctx.contents
+        return tuple(d2h(c.d_arr[k].contents.data, 3 * self.P, np.float64) for k in range(3))
+
+    def close(self):
+        lib().ParticleContextDestroy(self.ctx)
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(None, vp, vp, C.c_int32)
 HALO_FN = C.CFUNCTYPE(None, vp, vp)
 
@@ -247,8 +287,17 @@ def _declare(L):
     f("dfl_ddot", None, [i32, vp, vp, vp, vp, vp]); f("dfl_dnrm2", None, [i32, vp, vp, vp, vp])
     f("dfl_daxpy", None, [i32, f64, vp, vp, vp]); f("dfl_dscal", None, [i32, f64, vp, vp])
     f("dfl_pc_jacobi_setup", None, [i32, vp, vp, vp, vp, vp, vp]); f("dfl_pc_jacobi_apply", None, [i32, i32, vp, vp, vp, vp, vp])
-    f("dfl_assemble_tet_lhs", None, [i32, vp, vp, vp, vp, vp, vp])
-    f("dfl_assemble_tet_rhs", None, [i32, vp, i32, vp, vp, vp, vp, vp])
+    f("dfl_assemble_tet_lhs", None, [i32, vp, vp, vp, vp, vp])
+    f("dfl_assemble_tet_rhs", None, [i32, vp, vp, vp, vp])
+    f("dfl_pack_nodes", None, [i32, vp, vp, vp, vp, vp]); f("dfl_unpack_rhs", None, [i32, vp, vp, vp])
+    f("ParticleContextCreate", C.POINTER(ParticleContext), [i32]); f("ParticleContextDestroy", None, [C.POINTER(ParticleContext)])
+    f("ParticleContextUpdateDevice", None, [C.POINTER(ParticleContext)]); f("ParticleContextUpdateHost", None, [C.POINTER(ParticleContext)])
+    f("ParticleContextSetContactModel", None, [C.POINTER(ParticleContext), f64, f64, f64])
+    f("ParticleContextComputeForces", None, [C.POINTER(ParticleContext)]); f("ParticleContextUpdate", None, [C.POINTER(ParticleContext)])
+    f("SolveFlowSystem", i32, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix), vp, vp, vp, vp, i32, i32, vp, vp])
+    f("DflTimeStep", i32, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix), vp, vp, vp, vp, i32, i32, C.POINTER(ParticleContext),
+                           i32, vp, vp])
+    f("DflProfileEnable", None, [C.c_int]); f("DflProfileCollect", C.c_int, [C.c_int, C.POINTER(f64), C.POINTER(f64)])
     f("GenerateRandomColor", None, [vp, i32, i32])
     f("dfl_abi_version", C.c_int, [])
 
@@ -355,6 +404,20 @@ class Problem:
         st = lib().KrylovGetStats(self.ksp).contents
         it = int(st.iterations)
         return it, float(st.rnrm_init), np.array(st.res_hist[:min(it, 512)]), bool(st.converged)
+
+    def solve_flow_system(self, wgold, dwgold, dwg, F, dx, maxit=4):
+        """SolveFlowSystem (src/main.c:77-283); returns (newton_its, rnorm[4], rnorm_init[4])."""
+        rn, r0 = (C.c_double * 4)(), (C.c_double * 4)()
+        it = lib().SolveFlowSystem(self.mesh, wgold.ptr, dwgold.ptr, dwg.ptr, self.J, F.ptr, dx.ptr, self.ksp,
+                                   C.cast(self.bc_arr, vp), len(self.bcs), maxit, C.cast(rn, vp), C.cast(r0, vp))
+        return int(it), np.array(rn[:]), np.array(r0[:])
+
+    def time_step(self, wgold, dwgold, dwg, F, dx, newton_maxit=4, particles=None, dem_substeps=0):
+        rn, r0 = (C.c_double * 4)(), (C.c_double * 4)()
+        it = lib().DflTimeStep(self.mesh, wgold.ptr, dwgold.ptr, dwg.ptr, self.J, F.ptr, dx.ptr, self.ksp, C.cast(self.bc_arr, vp),
+                               len(self.bcs), newton_maxit, particles.ctx if particles is not None else None, dem_substeps,
+                               C.cast(rn, vp), C.cast(r0, vp))
+        return int(it), np.array(rn[:]), np.array(r0[:])
 
     def close(self):
         L = lib()

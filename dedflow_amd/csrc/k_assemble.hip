@@ -99,7 +99,7 @@ constexpr int LBLK = 256;
 constexpr int TRS = 257;  // padded row length of the transpose buffer
 
 __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict__ ien_b, const I* __restrict__ nzmap_b,
-                                                      const T* __restrict__ xg, const T* __restrict__ wg, T* __restrict__ val) {
+                                                      const T* __restrict__ nodep, T* __restrict__ val) {
     __shared__ double s_x[EPB][12];
     __shared__ double s_u[EPB][12];
     __shared__ double s_shg[EPB][12];
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict_
     if (valid && p < 12) {
         const int a = p / 3, d = p - a * 3;
         const long long node = ien_b[e * 4 + a];
-        s_x[te][p] = xg[3 * node + d];
-        s_u[te][p] = wg[3 * node + d];
+        s_x[te][p] = nodep[node * 16 + d];      // packed node record: x at [0..2], u at [3..5]
+        s_u[te][p] = nodep[node * 16 + 3 + d];
     }
     __syncthreads();
 
@@ -186,41 +186,51 @@ __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict_
             gb[d] = s_shg[te][bb * 3 + d];
         }
         const double eK = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+        // Every term of the reference's per-quadrature-point update (assemble.cu:618-661) is
+        // (quadrature-dependent scalar) x (quadrature-independent geometry product) x detJ*gw
+        // with equal weights, so the 4-point loop reduces to eleven scalar sums followed by ONE
+        // pass over the 16 block entries: ~5x fewer fp64 operations than the literal loop (the
+        // kernel was co-limited by the fp64 pipe).  Same terms, different association: results
+        // differ from the oracle by rounding only (tests bound it at 1e-10).
+        double S_t0 = 0.0, S_t1 = 0.0, S_sa = 0.0, S_sb = 0.0, S_sasb = 0.0, S_t0ca = 0.0, S_t0casb = 0.0, S_sacb = 0.0,
+               S_t0cacb = 0.0, S_t0sb = 0.0, S_t0cb = 0.0;
 #pragma unroll
         for (int iq = 0; iq < 4; ++iq) {
             const double tau0 = s_tau[te][iq][0], tau1 = s_tau[te][iq][1];
             const double ca = s_conv[te][aa][iq], cb = s_conv[te][bb][iq];
             const double sa = shl(aa, iq), sb = shl(bb, iq);
-            const double detJgw = detJ * GW;
-            double tmp = 0.0;
-            tmp += fact1 * kRHO * sa * sb;
-            tmp += fact1 * kRHO * kRHO * tau0 * ca * sb;
-            tmp += fact2 * sa * kRHO * cb;
-            tmp += fact2 * tau0 * kRHO * ca * kRHO * cb;
-            tmp += fact2 * kMU * eK;
-            Bk[0] += tmp * detJgw;
-            Bk[5] += tmp * detJgw;
-            Bk[10] += tmp * detJgw;
-#pragma unroll
-            for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-                for (int jj = 0; jj < 3; ++jj) {
-                    Bk[ii * 4 + jj] += fact2 * kMU * ga[jj] * gb[ii] * detJgw;
-                    Bk[ii * 4 + jj] += fact2 * kRHO * tau1 * ga[ii] * gb[jj] * detJgw;
-                }
-#pragma unroll
-            for (int ii = 0; ii < 3; ++ii) {  // dRM/dP
-                Bk[ii * 4 + 3] -= ga[ii] * sb * detJgw;
-                Bk[ii * 4 + 3] += kRHO * tau0 * ca * gb[ii] * detJgw;
-            }
-#pragma unroll
-            for (int ii = 0; ii < 3; ++ii) {  // dRC/dU
-                Bk[12 + ii] += fact1 * kRHO * tau0 * ga[ii] * sb * detJgw;
-                Bk[12 + ii] += fact2 * sa * gb[ii] * detJgw;
-                Bk[12 + ii] += fact2 * tau0 * ga[ii] * kRHO * cb * detJgw;
-            }
-            Bk[15] += tau0 * eK * detJgw;  // dRC/dP
+            const double t0ca = tau0 * ca;
+            S_t0 += tau0;
+            S_t1 += tau1;
+            S_sa += sa;
+            S_sb += sb;
+            S_sasb += sa * sb;
+            S_t0ca += t0ca;
+            S_t0casb += t0ca * sb;
+            S_sacb += sa * cb;
+            S_t0cacb += t0ca * cb;
+            S_t0sb += tau0 * sb;
+            S_t0cb += tau0 * cb;
         }
+        const double w = detJ * GW;
+        const double diag = w * (fact1 * kRHO * S_sasb + fact1 * kRHO * kRHO * S_t0casb + fact2 * kRHO * S_sacb +
+                                 fact2 * kRHO * kRHO * S_t0cacb + 4.0 * fact2 * kMU * eK);
+        const double cK = 4.0 * fact2 * kMU * w, cT = fact2 * kRHO * S_t1 * w;
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) Bk[ii * 4 + jj] = cK * ga[jj] * gb[ii] + cT * ga[ii] * gb[jj];
+        Bk[0] += diag;
+        Bk[5] += diag;
+        Bk[10] += diag;
+        const double cP0 = w * S_sb, cP1 = w * kRHO * S_t0ca;
+        const double cU0 = w * (fact1 * kRHO * S_t0sb + fact2 * kRHO * S_t0cb), cU1 = w * fact2 * S_sa;
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+            Bk[ii * 4 + 3] = cP1 * gb[ii] - cP0 * ga[ii];  // dRM/dP
+            Bk[12 + ii] = cU0 * ga[ii] + cU1 * gb[ii];     // dRC/dU
+        }
+        Bk[15] = w * S_t0 * eK;  // dRC/dP
     }
     // transpose through LDS: s_blk[i][t] = entry i of the block owned by thread t
 #pragma unroll
@@ -269,8 +279,13 @@ __device__ __forceinline__ double dpp_quad(double v) {
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict__ ien_b, I N, const T* __restrict__ xg,
-                                                      const T* __restrict__ wg, const T* __restrict__ dwg, T* __restrict__ F) {
+// node record of the packed gather layout (pack_nodes_kernel): one 128-byte line per node
+//   [0..2] x  [3..5] u  [6] phi  [7] T  [8..10] du  [11] p (from the rate vector, Q9)  [12] dphi  [13] dT
+constexpr int NREC = 16;
+constexpr int FREC = 8;  // packed residual record: F_u0 F_u1 F_u2 F_p F_phi F_T pad pad (64 bytes)
+
+__global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict__ ien_b, const T* __restrict__ nodep,
+                                                      T* __restrict__ Fp) {
     __shared__ double s_n[REPB][4][NV + 1];
     const int t = threadIdx.x;
     const int te = t >> 2, a = t & 3;
@@ -280,14 +295,13 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
     if (valid) {
         node = ien_b[e * 4 + a];
         double* s = s_n[te][a];
-        s[0] = xg[3 * node]; s[1] = xg[3 * node + 1]; s[2] = xg[3 * node + 2];
-        s[3] = wg[3 * node]; s[4] = wg[3 * node + 1]; s[5] = wg[3 * node + 2];
-        s[6] = wg[4LL * N + node];
-        s[7] = wg[5LL * N + node];
-        s[8] = dwg[3 * node]; s[9] = dwg[3 * node + 1]; s[10] = dwg[3 * node + 2];
-        s[11] = dwg[3LL * N + node];  // pressure always from the rate vector (Q9, :1606-1609)
-        s[12] = dwg[4LL * N + node];
-        s[13] = dwg[5LL * N + node];
+        const double2* rec = reinterpret_cast<const double2*>(nodep + node * NREC);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {  // 7 x 16 B out of one line instead of 14 scattered 8-byte gathers
+            const double2 v = rec[k];
+            s[2 * k] = v.x;
+            s[2 * k + 1] = v.y;
+        }
     }
     __syncthreads();
     if (!valid) return;  // whole 4-lane groups leave together; shuffles below stay inside a group
@@ -434,13 +448,53 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
         const double keep = hi1 ? r1 : r0, send = hi1 ? r0 : r1;
         mine[j] = keep + dpp_quad<0xB1>(send);
     }
-    // ElemRHSLocal2Global: non-atomic, race-free inside a color
-    F[3 * node + 0] += mine[0];
-    F[3 * node + 1] += mine[1];
-    F[3 * node + 2] += mine[2];
-    F[3LL * N + node] += mine[3];
-    F[4LL * N + node] += mine[4];
-    F[5LL * N + node] += mine[5];
+    // ElemRHSLocal2Global: non-atomic, race-free inside a class; one 64-byte record per node
+    double2* dst = reinterpret_cast<double2*>(Fp + node * FREC);
+    double2 f0 = dst[0], f1 = dst[1], f2 = dst[2];
+    f0.x += mine[0]; f0.y += mine[1];
+    f1.x += mine[2]; f1.y += mine[3];
+    f2.x += mine[4]; f2.y += mine[5];
+    dst[0] = f0; dst[1] = f1; dst[2] = f2;
+}
+
+// gather layout: one line per node, written once per assembly call from the reference-layout vectors
+__global__ __launch_bounds__(256) void pack_nodes_kernel(I N, const T* __restrict__ xg, const T* __restrict__ wg,
+                                                        const T* __restrict__ dwg, T* __restrict__ nodep) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    double r[NREC];
+    r[0] = xg[3 * i]; r[1] = xg[3 * i + 1]; r[2] = xg[3 * i + 2];
+    r[3] = wg[3 * i]; r[4] = wg[3 * i + 1]; r[5] = wg[3 * i + 2];
+    r[6] = wg[4LL * N + i];
+    r[7] = wg[5LL * N + i];
+    if (dwg) {
+        r[8] = dwg[3 * i]; r[9] = dwg[3 * i + 1]; r[10] = dwg[3 * i + 2];
+        r[11] = dwg[3LL * N + i];  // pressure always from the rate vector (Q9, assemble.cu:1606-1609)
+        r[12] = dwg[4LL * N + i];
+        r[13] = dwg[5LL * N + i];
+    } else {
+        r[8] = r[9] = r[10] = r[11] = r[12] = r[13] = 0.0;
+    }
+    r[14] = r[15] = 0.0;
+    double2* o = reinterpret_cast<double2*>(nodep + i * NREC);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = make_double2(r[2 * k], r[2 * k + 1]);
+}
+
+// F (reference layout) += packed residual; the packed buffer is cleared for the next call
+__global__ __launch_bounds__(256) void unpack_rhs_kernel(I N, T* __restrict__ Fp, T* __restrict__ F) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    double2* src = reinterpret_cast<double2*>(Fp + i * FREC);
+    const double2 f0 = src[0], f1 = src[1], f2 = src[2];
+    F[3 * i + 0] += f0.x;
+    F[3 * i + 1] += f0.y;
+    F[3 * i + 2] += f1.x;
+    F[3LL * N + i] += f1.y;
+    F[4LL * N + i] += f2.x;
+    F[5LL * N + i] += f2.y;
+    const double2 z = make_double2(0.0, 0.0);
+    src[0] = z; src[1] = z; src[2] = z;
 }
 
 // ====================================================================================
@@ -639,15 +693,27 @@ __global__ __launch_bounds__(256) void gather_ien_kernel(I T_, const I* __restri
 
 extern "C" {
 
-void dfl_assemble_tet_lhs(I B, const I* ien_b, const I* nzmap_b, const T* xg, const T* wg, T* val, void* stream) {
+void dfl_assemble_tet_lhs(I B, const I* ien_b, const I* nzmap_b, const T* nodep, T* val, void* stream) {
     if (B <= 0) return;
-    tet_lhs_kernel<<<ceil_div(B, EPB), LBLK, 0, S(stream)>>>(B, ien_b, nzmap_b, xg, wg, val);
+    tet_lhs_kernel<<<ceil_div(B, EPB), LBLK, 0, S(stream)>>>(B, ien_b, nzmap_b, nodep, val);
     DFL_LAUNCH_CHECK();
 }
 
-void dfl_assemble_tet_rhs(I B, const I* ien_b, I N, const T* xg, const T* wg, const T* dwg, T* F, void* stream) {
+void dfl_assemble_tet_rhs(I B, const I* ien_b, const T* nodep, T* Fp, void* stream) {
     if (B <= 0) return;
-    tet_rhs_kernel<<<ceil_div(B, REPB), RBLK, 0, S(stream)>>>(B, ien_b, N, xg, wg, dwg, F);
+    tet_rhs_kernel<<<ceil_div(B, REPB), RBLK, 0, S(stream)>>>(B, ien_b, nodep, Fp);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_pack_nodes(I N, const T* xg, const T* wg, const T* dwg, T* nodep, void* stream) {
+    if (N <= 0) return;
+    pack_nodes_kernel<<<ceil_div(N, 256), 256, 0, S(stream)>>>(N, xg, wg, dwg, nodep);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_unpack_rhs(I N, T* Fp, T* F, void* stream) {
+    if (N <= 0) return;
+    unpack_rhs_kernel<<<ceil_div(N, 256), 256, 0, S(stream)>>>(N, Fp, F);
     DFL_LAUNCH_CHECK();
 }
 

@@ -110,6 +110,14 @@ __global__ __launch_bounds__(BLK) void scal_inv_dev(I n, const T* d_scale, T* x)
     if (i == 0 && (n & 1)) x[n - 1] *= s;
 }
 
+// Krylov basis columns are streamed once per pass (2.3 GB at 10M tets, m = 40): nontemporal
+// loads keep them from displacing w and the partial sums in L2 / MALL.
+typedef double d2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld_stream(const T* p) {
+    const d2s v = __builtin_nontemporal_load(reinterpret_cast<const d2s*>(p));
+    return make_double2(v.x, v.y);
+}
+
 // ---- fused CGS -------------------------------------------------------------------
 // d_h[j] = Q[:,j].w : grid (row blocks, column tiles of CT); each thread owns
 // RPT double2 row slots, keeps w in registers across the CT columns of its tile.
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(BLK) void cgs_dots_stage1(I n, I ncol, const T* __r
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             double2 qv;
-            if (row[i] + 1 < n) qv = *reinterpret_cast<const double2*>(q + row[i]);
+            if (row[i] + 1 < n) qv = ld_stream(q + row[i]);
             else { qv.x = (row[i] < n) ? q[row[i]] : 0.0; qv.y = 0.0; }
             acc += qv.x * wv[i].x + qv.y * wv[i].y;
         }
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(BLK) void cgs_update_kernel(I n, I ncol, const T* _
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
             double2 qv;
-            if (row[i] + 1 < n) qv = *reinterpret_cast<const double2*>(q + row[i]);
+            if (row[i] + 1 < n) qv = ld_stream(q + row[i]);
             else { qv.x = (row[i] < n) ? q[row[i]] : 0.0; qv.y = 0.0; }
             if (SUB) { acc[i].x -= qv.x * h; acc[i].y -= qv.y * h; }
             else { acc[i].x += qv.x * h; acc[i].y += qv.y * h; }

@@ -16,7 +16,17 @@ constexpr int BLK = 256;
 // x index of block column c (0..3) of node `col` in the [u AoS | p] layout
 __device__ __forceinline__ long long xidx(int col, int c, long long N3) { return c < 3 ? 3LL * col + c : N3 + col; }
 
-template <bool BETA0>
+typedef double d2v __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ d2v ld_val(const d2v* p) {
+    // the 3.3 GB value stream is read exactly once per matvec: nontemporal keeps it from
+    // evicting the gathered x (55 MB at 10M tets) out of L2 / MALL
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
+// U nodal nonzeros per loop trip: all U index loads, then all U value loads, then the 2U
+// gathers are issued before the first FMA -- more bytes in flight per 8-lane row group
+template <bool BETA0, bool NT, int U>
 __global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I nrows, I N, const I* __restrict__ rp, const I* __restrict__ ci,
                                                        const T* __restrict__ val, T alpha, const T* __restrict__ x, T beta,
                                                        T* __restrict__ y) {
@@ -28,34 +38,47 @@ __global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I nrows, I N, const I* _
     const int r = l >> 1;
     const bool hi = (l & 1);  // false: columns (u0,u1); true: columns (u2,p)
     const int s = rp[row], e = rp[row + 1];
-    const double2* __restrict__ v2 = reinterpret_cast<const double2*>(val) + l;
-    double acc0 = 0.0, acc1 = 0.0;
+    const d2v* __restrict__ v2 = reinterpret_cast<const d2v*>(val) + l;
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0.0;
     int k = s;
-    for (; k + 1 < e; k += 2) {
-        const int c0 = ci[k], c1 = ci[k + 1];
-        const double2 a0 = v2[(long long)k * 8];
-        const double2 a1 = v2[(long long)(k + 1) * 8];
-        const double x00 = hi ? x[3LL * c0 + 2] : x[3LL * c0];
-        const double x01 = hi ? x[N3 + c0] : x[3LL * c0 + 1];
-        const double x10 = hi ? x[3LL * c1 + 2] : x[3LL * c1];
-        const double x11 = hi ? x[N3 + c1] : x[3LL * c1 + 1];
-        acc0 += a0.x * x00 + a0.y * x01;
-        acc1 += a1.x * x10 + a1.y * x11;
+    for (; k + U <= e; k += U) {
+        int c[U];
+        d2v a[U];
+        double xa[U], xb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = ci[k + u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = ld_val<NT>(v2 + (long long)(k + u) * 8);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long ia = hi ? 3LL * c[u] + 2 : 3LL * c[u];
+            const long long ib = hi ? N3 + c[u] : 3LL * c[u] + 1;
+            xa[u] = x[ia];
+            xb[u] = x[ib];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] += a[u].x * xa[u] + a[u].y * xb[u];
     }
-    if (k < e) {
+    for (; k < e; ++k) {
         const int c0 = ci[k];
-        const double2 a0 = v2[(long long)k * 8];
-        const double x00 = hi ? x[3LL * c0 + 2] : x[3LL * c0];
-        const double x01 = hi ? x[N3 + c0] : x[3LL * c0 + 1];
-        acc0 += a0.x * x00 + a0.y * x01;
+        const d2v a0 = ld_val<NT>(v2 + (long long)k * 8);
+        const long long ia = hi ? 3LL * c0 + 2 : 3LL * c0;
+        const long long ib = hi ? N3 + c0 : 3LL * c0 + 1;
+        acc[0] += a0.x * x[ia] + a0.y * x[ib];
     }
-    double acc = acc0 + acc1;
-    acc += __shfl_xor(acc, 1, WAVE);
+    double tot = acc[0];
+#pragma unroll
+    for (int u = 1; u < U; ++u) tot += acc[u];
+    tot += __shfl_xor(tot, 1, WAVE);
     if (!hi) {
         const long long yi = xidx(row, r, N3);
-        y[yi] = BETA0 ? alpha * acc : alpha * acc + beta * y[yi];
+        y[yi] = BETA0 ? alpha * tot : alpha * tot + beta * y[yi];
     }
 }
+
+int g_spmv_variant = 3;
 
 // scalar CSR, 8 lanes per row (reference-layout sub-matrices)
 __global__ __launch_bounds__(BLK) void csr_spmv_kernel(I nrow, const I* __restrict__ rp, const I* __restrict__ ci,
@@ -267,9 +290,23 @@ extern "C" {
 void dfl_bcsr_spmv_rows(I nrows, I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
     if (nrows <= 0) return;
     const int grid = ceil_div((long long)nrows * 8, BLK);
-    if (beta == 0.0) bcsr_spmv_kernel<true><<<grid, BLK, 0, S(stream)>>>(nrows, N, rp, ci, val, alpha, x, beta, y);
-    else bcsr_spmv_kernel<false><<<grid, BLK, 0, S(stream)>>>(nrows, N, rp, ci, val, alpha, x, beta, y);
+#define SPMV_LAUNCH(B0, NTV, UV) bcsr_spmv_kernel<B0, NTV, UV><<<grid, BLK, 0, S(stream)>>>(nrows, N, rp, ci, val, alpha, x, beta, y)
+    if (beta == 0.0) {
+        switch (g_spmv_variant) {
+            case 0: SPMV_LAUNCH(true, false, 2); break;
+            case 1: SPMV_LAUNCH(true, true, 2); break;
+            case 2: SPMV_LAUNCH(true, false, 4); break;
+            default: SPMV_LAUNCH(true, true, 4); break;
+        }
+    } else {
+        SPMV_LAUNCH(false, true, 4);
+    }
+#undef SPMV_LAUNCH
     DFL_LAUNCH_CHECK();
+}
+/* kernel-variant selection for A/B measurements (key 0: block-CSR SpMV variant 0..3) */
+void dfl_tune(int key, int value) {
+    if (key == 0) g_spmv_variant = value;
 }
 void dfl_bcsr_spmv(I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
     dfl_bcsr_spmv_rows(N, N, rp, ci, val, alpha, x, beta, y, stream);

@@ -46,6 +46,12 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
         spy = block_pattern(J, &val);
         ensure_nzmap(mesh, spy);
     }
+    /* packed gather records (one line per node) and packed residual accumulator */
+    if (!x->nodep) {
+        x->nodep = (f64*)CdamMallocDevice((ptrdiff_t)N * 16 * SIZE_OF(f64));
+        x->Fp = (f64*)CdamMallocDevice((ptrdiff_t)N * 8 * SIZE_OF(f64));
+    }
+    dfl_pack_nodes(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, x->nodep, s);
     /* one launch per class of the execution schedule (mesh.c: the reference's color batches in
        mode 0, the compact re-coloring otherwise) */
     for (index_type b = 0; b < x->sched_num; ++b) {
@@ -53,9 +59,10 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
         const index_type bsz = x->sched_offset[b + 1] - off;
         if (bsz == 0) continue;
         const index_type* ien_b = x->ien_b + (size_t)off * 4;
-        if (F) DFL_TIMED(DFL_TAG_ASM_RHS, dfl_assemble_tet_rhs(bsz, ien_b, N, dev->xg, wgalpha_dptr, dwgalpha_dptr, F, s));
-        if (J) DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, dev->xg, wgalpha_dptr, val, s));
+        if (F) DFL_TIMED(DFL_TAG_ASM_RHS, dfl_assemble_tet_rhs(bsz, ien_b, x->nodep, x->Fp, s));
+        if (J) DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, x->nodep, val, s));
     }
+    if (F) dfl_unpack_rhs(N, x->Fp, F, s);
 }
 
 void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J) {

@@ -14,6 +14,8 @@ typedef struct MeshExt {
     index_type* face_color_offset; /* host [face_num_class+1] */
     index_type face_num_class;     /* conflict-free face classes (greedy node coloring of the group's faces) */
     index_type* h_f2e;             /* host copy of bound_f2e */
+    f64* nodep;                    /* device [N][16] packed gather records (x,u,phi,T,du,p,dphi,dT) */
+    f64* Fp;                       /* device [N][8] packed residual accumulator, zero between calls */
 } MeshExt;
 
 void DflMeshPrepareFaces(Mesh3D* mesh, index_type group);
@@ -29,4 +31,7 @@ void DflProfileEnd(int slot);
 int DflProfileCollect(int tag, double* total_ms, double* min_ms);
 #define DFL_TIMED(tag, call) do { int _s = DflProfileBegin(tag); call; DflProfileEnd(_s); } while (0)
 
+/* driver.c */
+index_type SolveFlowSystem(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* J, f64* F, f64* dx, Krylov* ksp,
+                           Dirichlet** bcs, index_type nbc, index_type maxit, f64* rnorm_out, f64* rnorm_init_out);
 #endif

@@ -91,6 +91,8 @@ void Mesh3DDestroy(Mesh3D* m) {
     if (x) {
         CdamFreeDevice(x->ien_b, 0);
         CdamFreeDevice(x->nzmap_b, 0);
+        CdamFreeDevice(x->nodep, 0);
+        CdamFreeDevice(x->Fp, 0);
         CdamFreeDevice(x->face_list, 0);
         if (x->face_color_offset) CdamFreeHost(x->face_color_offset, 0);
         if (x->sched_offset) CdamFreeHost(x->sched_offset, 0);

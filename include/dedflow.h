@@ -358,6 +358,17 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
 void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J);
 /* the caller of the hot path, src/main.c:31-75 (static there) */
 void AssembleSystem(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, Dirichlet** bcs, index_type nbc);
+/* generalized-alpha Newton solve of one time level (src/main.c:77-283, static there; `maxit` <= 0 -> 4).
+ * Returns the Newton iteration count; rnorm_out / rnorm_init_out (4 each: u, p, phi, T) may be NULL. */
+index_type SolveFlowSystem(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* J, f64* F, f64* dx, Krylov* ksp,
+                           Dirichlet** bcs, index_type nbc, index_type maxit, f64* rnorm_out, f64* rnorm_init_out);
+struct ParticleContext;
+/* one pass of the time loop body (src/main.c:537-565): predictor, SolveFlowSystem, corrector; with a
+ * particle context also `dem_substeps` contact sweeps + particle updates (the calls the reference has
+ * commented out at main.c:547-569) */
+index_type DflTimeStep(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* J, f64* F, f64* dx, Krylov* ksp, Dirichlet** bcs,
+                       index_type nbc, index_type newton_maxit, struct ParticleContext* pctx, index_type dem_substeps,
+                       f64* rnorm_out, f64* rnorm_init_out);
 void DflSetQuiet(b32 quiet); /* suppress the reference's stdout chatter ("Assemble: F J", timers) */
 /* which conflict-free launches the assembly kernels execute (set BEFORE Mesh3DGenerateColorBatch):
  *   0  the reference's JPL color batches, one launch per color (reference summation order)

@@ -180,20 +180,35 @@ dfl_index dfl_count_priority_ties(const dfl_index* ien, dfl_index T, const dfl_i
                                   const dfl_index* prio);
 
 /* ---- element assembly, one launch per color batch (src/assemble.cu:1559-1738 chain fused).
- *  ien_b / nzmap_b point at the first element of the batch (batch-ordered arrays). */
-void dfl_assemble_tet_lhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_index* nzmap_b, const dfl_value* xg,
-                          const dfl_value* wgalpha, dfl_value* val, void* stream);
-void dfl_assemble_tet_rhs(dfl_index batch_size, const dfl_index* ien_b, dfl_index N, const dfl_value* xg,
-                          const dfl_value* wgalpha, const dfl_value* dwgalpha, dfl_value* F, void* stream);
+ *  ien_b / nzmap_b point at the first element of the batch (batch-ordered arrays).
+ *  Node data is gathered from a packed per-node record array (one 128-byte line per node:
+ *  x[3] u[3] phi T du[3] p dphi dT pad pad) written once per assembly call by dfl_pack_nodes --
+ *  replaces the 8 LoadElementValueKernel launches per batch (assemble.cu:1601-1619,1663-1678).
+ *  The RHS kernel accumulates into packed 64-byte residual records (F_u[3] F_p F_phi F_T pad pad);
+ *  dfl_unpack_rhs adds them to F in the reference layout and clears the packed buffer. */
+void dfl_pack_nodes(dfl_index N, const dfl_value* xg, const dfl_value* wgalpha, const dfl_value* dwgalpha /*or NULL*/,
+                    dfl_value* nodep /*[N][16]*/, void* stream);
+void dfl_unpack_rhs(dfl_index N, dfl_value* Fp /*[N][8], zeroed on return*/, dfl_value* F, void* stream);
+void dfl_assemble_tet_lhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_index* nzmap_b, const dfl_value* nodep,
+                          dfl_value* val, void* stream);
+void dfl_assemble_tet_rhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_value* nodep, dfl_value* Fp, void* stream);
 /* weak-BC faces of one color (src/assemble.cu:1764-1964): face list entries index f2e/forn of the group */
 void dfl_assemble_face(dfl_index n_face, const dfl_index* face_list, const dfl_index* f2e, const dfl_index* forn,
                        const dfl_index* ien, dfl_index N, const dfl_value* xg, const dfl_value* wgalpha,
                        const dfl_value* dwgalpha, dfl_value* F /*or NULL*/, const dfl_index* row_ptr, const dfl_index* col_ind,
                        dfl_value* val /*or NULL*/, void* stream);
 
-/* ---- DEM contact sweep (build-defined; the reference's Particle.c holds storage only) */
-void dfl_dem_cell_index(dfl_index P, const dfl_value* coord, dfl_value cell, dfl_index ncell, dfl_index* cell_id, void* stream);
+/* ---- DEM contact sweep (build-defined; the reference's Particle.c holds storage only)
+ *  model: monodisperse spheres, linear spring-dashpot normal contact F = (kn*overlap - gamma_n*vn) n between
+ *  particles and against the six walls of the unit box; uniform cell list with cell edge >= 2R:
+ *    dfl_dem_cell_index   cell_id[i] = cx + ncell*(cy + ncell*cz), order[i] = i
+ *    dfl_dem_sort_by_cell stable sort of (cell_id, order) by cell; cell_start[ncell^3 + 1]; synchronises, allocates temp
+ *    dfl_dem_forces       acc[i] = (sum_j F_ij + F_walls) / mass, neighbours from the 27 surrounding cells
+ *    dfl_dem_integrate    v += dt*a ; x += dt*v */
+void dfl_dem_cell_index(dfl_index P, const dfl_value* coord, dfl_value cell, dfl_index ncell, dfl_index* cell_id,
+                        dfl_index* order, void* stream);
 void dfl_dem_sort_by_cell(dfl_index P, dfl_index* cell_id, dfl_index* order, dfl_index ncell3, dfl_index* cell_start);
+void dfl_dem_integrate(dfl_index P, dfl_value dt, dfl_value* coord, dfl_value* vel, const dfl_value* acc, void* stream);
 void dfl_dem_forces(dfl_index P, const dfl_value* coord, const dfl_value* vel, dfl_value radius, dfl_value mass, dfl_value kn,
                     dfl_value gamma_n, dfl_value cell, dfl_index ncell, const dfl_index* order, const dfl_index* cell_start,
                     dfl_value* acc, void* stream);

@@ -244,3 +244,13 @@ def elem_heat(xg, nodes):
     J = np.empty(16)
     lib().orc_elem_heat(_p(xg), _p(np.asarray(nodes, np.int32)), _p(J))
     return J.reshape(4, 4)
+
+
+def dem_forces(x, v, R, mass=1.0, kn=1.0e4, gn=1.0, brute=False):
+    """Build-defined DEM contact sweep (oracle_ext.cpp); returns (acc[3P], tested pair count)."""
+    P = x.size // 3
+    acc = np.empty(3 * P)
+    tested = C.c_longlong(0)
+    lib().orc_dem_forces(C.c_int(P), _p(np.ascontiguousarray(x)), _p(np.ascontiguousarray(v)), C.c_double(R), C.c_double(mass),
+                         C.c_double(kn), C.c_double(gn), C.c_int(1 if brute else 0), _p(acc), C.byref(tested))
+    return acc, int(tested.value)

@@ -1,0 +1,34 @@
+"""A/B timing of block-CSR SpMV kernel variants (dfl_tune key 0) on the 10M-tet matrix,
+interleaved in one process (cdna_hip_programming.md rule 24)."""
+import ctypes as C, sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dedflow_amd import api
+from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 119
+mesh = kuhn_cube(M, jitter=0.2)
+wg, dwg = synthetic_fields(mesh)
+P = api.Problem(mesh)
+L = api.lib()
+L.dfl_tune.argtypes = [C.c_int, C.c_int]
+wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+P.assemble_system(wg_d, dwg_d, None, want_J=True)
+x = api.DeviceArray.from_numpy(np.random.default_rng(0).normal(size=6 * P.N))
+y = api.DeviceArray(6 * P.N)
+nbytes = 132.0 * P.nnz1 + 4.0 * (P.N + 1) + 64.0 * P.N
+t = api.Timer()
+res = {v: [] for v in range(4)}
+for rep in range(6):
+    for v in range(4):
+        L.dfl_tune(0, v)
+        P.matvec(x, y)
+        t.start()
+        for _ in range(10):
+            P.matvec(x, y)
+        t.stop()
+        res[v].append(t.ms() / 10)
+for v in range(4):
+    a = np.array(res[v][1:])
+    print("variant %d (NT=%d U=%d): median %.4f ms  min %.4f  -> %.0f GB/s (%.3f of 8 TB/s)" %
+          (v, v & 1, 2 if v < 2 else 4, np.median(a), a.min(), nbytes / np.median(a) / 1e6, nbytes / np.median(a) / 1e6 / 8000))
