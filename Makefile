@@ -14,7 +14,18 @@ KOBJ = $(KSRC:.hip=.o)
 HOBJ = $(HSRC:.c=.o)
 LIB  = dedflow_amd/libdedflow.so
 
-all: $(LIB)
+H5LIB  = dedflow_amd/libdedflow_h5.so
+HDF5   ?= /opt/conda
+
+all: $(LIB) $(H5LIB)
+
+# HDF5 mesh / solution formats (reference schema) in their own library: the core library has no
+# HDF5 dependency.  HDF5 1.10.6 C library of the image.
+$(H5LIB): dedflow_amd/h5/h5io.c include/dedflow.h $(LIB)
+	@if [ -f $(HDF5)/include/hdf5.h ]; then \
+	  $(CC) $(CFLAGS) -I$(HDF5)/include -shared $< -o $@ -Ldedflow_amd -ldedflow -L$(HDF5)/lib -lhdf5 \
+	    -Wl,-rpath,$(HDF5)/lib -Wl,-rpath,'$$ORIGIN'; \
+	else echo "HDF5 headers not found under $(HDF5): skipping $@"; fi
 
 dedflow_amd/csrc/%.o: dedflow_amd/csrc/%.hip dedflow_amd/csrc/dfl_common.hpp include/dedflow_kernels.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

@@ -163,8 +163,19 @@ def main():
     per_launch_bytes = {"spmv": ab["spmv"], "asm_lhs": ab["asm_lhs"] * K / max(kd["launches"], 1),
                         "asm_rhs": ab["asm_rhs"] * K / max(kd["launches"], 1), "pc_apply": ab["pc_apply"],
                         "cgs": sum(ab["cgs"]) * K / max(kd["launches"], 1)}[dominant]
+    # HBM traffic per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+    # --pmc WRITE_SIZE in separate runs, gfx950 x2 read correction as MI355X_MICROARCH.md prescribes).  It is a
+    # property of kernel + input, so it is only reported for the configuration it was collected on.
+    traffic = None
+    try:
+        if args.M == 119:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_M119.json")))
+            if dominant in pmc:
+                traffic = pmc[dominant]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": kd["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kd["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                "frac": kd["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": kd["avg_ms"]}
 
     cpu = cpu_baseline(args.cpu_M, its) if args.cpu_M > 0 else None

@@ -161,6 +161,22 @@ void Mesh3DSetBound(Mesh3D* mesh, index_type num_bound, const index_type* node_o
 void ColorMeshTet(const Mesh3D* mesh, index_type max_color_len, color_t* color);
 color_t GetMaxColor(const color_t* color, index_type num_elem);
 
+/* ---- HDF5 formats (h5util.h:24-58; implemented in libdedflow_h5.so, dedflow_amd/h5/h5io.c) ----- */
+H5FileInfo* H5OpenFile(const char* filename, const char* mode);
+void H5CloseFile(H5FileInfo* h5file);
+b32 H5DatasetExist(H5FileInfo* h5file, const char* dataset_name);
+void H5GetDatasetSize(H5FileInfo* h5file, const char* dataset_name, index_type* size);
+void H5ReadDatasetf64(H5FileInfo* h5file, const char* dataset_name, f64* data);
+void H5ReadDatasetInd(H5FileInfo* h5file, const char* dataset_name, index_type* data);
+void H5WriteDatasetf64(H5FileInfo* h5file, const char* dataset_name, index_type len, const f64* data);
+void H5WriteDatasetInd(H5FileInfo* h5file, const char* dataset_name, index_type len, const index_type* data);
+/* mesh writer in the schema tools/mesh_convert.py:116-126 produces; solution files of main.c:521-532,571-590 */
+void DflMeshWriteH5(H5FileInfo* f, const char* group, index_type N, index_type T, const f64* xg, const index_type* ien,
+                    index_type nb, const index_type* node_offset, const index_type* node, const index_type* elem_offset,
+                    const index_type* bien, const index_type* f2e, const index_type* forn);
+void DflSolutionWriteH5(const char* filename, index_type N, const f64* d_wgold, const f64* d_dwgold);
+void DflSolutionReadH5(const char* filename, index_type N, f64* d_wgold, f64* d_dwgold);
+
 /* ---- sparsity (csr.h) ------------------------------------------------------------ */
 typedef index_type csr_index_type;
 typedef struct CSRAttr CSRAttr;
