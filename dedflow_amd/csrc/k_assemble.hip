@@ -38,6 +38,18 @@ namespace {
 
 __device__ __forceinline__ double shl(int a, int q) { return a == q ? SHA : SHB; }
 
+// All lanes that cooperate on one element (16 in the LHS kernel, 4 in the RHS kernel) sit in ONE
+// wave, and every LDS slot is written and read by the same wave, so no workgroup barrier is
+// needed: LDS operations of a wave complete in order once lgkmcnt drains.  Waves of a block then
+// run their gather / compute / scatter phases independently (better latency hiding than four
+// s_barrier rendezvous per block).
+#define WAVE_SYNC()                                          \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
 __constant__ double c_shlub[48] = {
     0.0, GWB, GWB, 0.6666666666666667, 0.0, GWB, 0.6666666666666667, GWB, 0.0, 0.6666666666666667, GWB, GWB,
     GWB, 0.0, GWB, 0.6666666666666667, GWB, 0.0, 0.6666666666666667, GWB, 0.6666666666666667, 0.0, GWB, GWB,
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict_
         s_x[te][p] = nodep[node * 16 + d];      // packed node record: x at [0..2], u at [3..5]
         s_u[te][p] = nodep[node * 16 + 3 + d];
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     if (valid && p == 0) {
         double invJ[9], shg[12], G[9], detJ;
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict_
         s_scal[te][1] = gg;
         s_scal[te][2] = 1.0 / tr;
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     if (valid) {  // p = a*4 + q : shconv[a] at quadrature point q (:574-583)
         const int a = p >> 2, q = p & 3;
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict_
         c += s_shg[te][a * 3 + 2] * uq[2];
         s_conv[te][a][q] = c;
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     if (valid && p < 4) {  // stabilisation parameters at quadrature point p (:587-603)
         const double knu = kMU / kRHO;
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict_
         s_tau[te][p][0] = (1.0 / sqrt(4.0 / (kDT * kDT) + tmp + 3.0 * knu * knu * gg)) / kRHO;
         s_tau[te][p][1] = sqrt(tmp + 3.0 * knu * knu * gg) * s_scal[te][2];
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     double Bk[16];
 #pragma unroll
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict_
     // transpose through LDS: s_blk[i][t] = entry i of the block owned by thread t
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_blk[i * TRS + t] = Bk[i];
-    __syncthreads();
+    WAVE_SYNC();
 
     // scatter: 8 lanes per 128-byte block line, 32 blocks per pass, 8 passes
     const int l8 = t & 7;
@@ -243,14 +255,14 @@ __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict_
     long long addr[8];
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
-        const int bi = (t >> 3) + 32 * pass;
+        const int bi = (t & ~63) + ((t & 63) >> 3) + 8 * pass;
         const int nz = s_nz[bi];
         addr[pass] = (nz >= 0) ? ((long long)nz * 16 + 2 * l8) : -1;
         if (nz >= 0) oldv[pass] = *reinterpret_cast<const double2*>(val + addr[pass]);
     }
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
-        const int bi = (t >> 3) + 32 * pass;
+        const int bi = (t & ~63) + ((t & 63) >> 3) + 8 * pass;
         if (addr[pass] >= 0) {
             double2 nv;
             nv.x = oldv[pass].x + s_blk[(2 * l8) * TRS + bi];
@@ -303,7 +315,7 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
             s[2 * k + 1] = v.y;
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
     if (!valid) return;  // whole 4-lane groups leave together; shuffles below stay inside a group
 
     const int iq = a;

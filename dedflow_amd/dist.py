@@ -140,6 +140,13 @@ class HaloPlan:
             self.send_idx[q] = self._dof_index(pos, n)
         self.neighbours = sorted(set(self.recv_idx) | set(self.send_idx))
         self.bytes_per_exchange = 8 * sum(int(v.numel()) for v in self.send_idx.values())
+        # one-collective form (NCCL/RCCL all_to_all_single): concatenated index lists in rank order
+        self.send_splits = [int(self.send_idx[q].numel()) if q in self.send_idx else 0 for q in range(self.world)]
+        self.recv_splits = [int(self.recv_idx[q].numel()) if q in self.recv_idx else 0 for q in range(self.world)]
+        empty = torch.zeros(0, dtype=torch.int64, device=device)
+        self.send_all = torch.cat([self.send_idx.get(q, empty) for q in range(self.world)]) if self.world else empty
+        self.recv_all = torch.cat([self.recv_idx.get(q, empty) for q in range(self.world)]) if self.world else empty
+        self.use_all_to_all = (not use_host_staging) and dist.get_backend() == "nccl"
 
     def _dof_index(self, nodes, n):
         """flat indices of the 4 (u0,u1,u2,p) dofs of each node in the local [u|p|...] layout"""
@@ -150,6 +157,13 @@ class HaloPlan:
     def exchange(self, x):
         """x: torch f64 tensor (local vector, on self.device); fills the ghost dofs in place."""
         torch, dist = self.torch, self.dist
+        if self.use_all_to_all:
+            # xGMI is a full mesh: one grouped send/recv launch to all neighbours at once
+            send = x.index_select(0, self.send_all)
+            recv = torch.empty(self.recv_all.numel(), dtype=x.dtype, device=self.device)
+            dist.all_to_all_single(recv, send, self.recv_splits, self.send_splits)
+            x.index_copy_(0, self.recv_all, recv)
+            return
         ops, recv_bufs = [], {}
         for q in self.neighbours:
             if q in self.send_idx:
@@ -179,6 +193,7 @@ class TorchDeviceAllocator:
         self.torch, self.device = torch, device
         self.blocks = {}   # base ptr -> uint8 tensor
         self.bases = []
+        self._views = {}   # (ptr, n) -> (base, f64 view): the GMRES loop asks for the same few buffers
         MALLOC = C.CFUNCTYPE(C.c_void_p, C.c_ssize_t, C.c_void_p)
         FREE = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p)
 
@@ -198,6 +213,7 @@ class TorchDeviceAllocator:
             if ptr and ptr in self.blocks:
                 del self.blocks[ptr]
                 self.bases = sorted(self.blocks)
+                self._views.clear()
 
         self._m, self._f = MALLOC(_malloc), FREE(_free)
         L = api.lib()
@@ -210,12 +226,20 @@ class TorchDeviceAllocator:
         """f64 view of n elements at raw device pointer `ptr` (must lie in one of our blocks)."""
         import bisect
         torch = self.torch
+        key = (ptr, n)
+        hit = self._views.get(key)
+        if hit is not None and hit[0] in self.blocks:
+            return hit[1]
         i = bisect.bisect_right(self.bases, ptr) - 1
         base = self.bases[i]
         blk = self.blocks[base]
         off = ptr - base
         assert 0 <= off and off + 8 * n <= blk.numel(), "pointer outside torch-allocated device memory"
-        return blk[off:off + 8 * n].view(torch.float64)
+        v = blk[off:off + 8 * n].view(torch.float64)
+        if len(self._views) > 4096:
+            self._views.clear()
+        self._views[key] = (base, v)
+        return v
 
 
 class DistSolverComm:

@@ -86,6 +86,7 @@ def run(args, rank, world, local_rank):
 
     for _ in range(args.warmup):
         step()
+    L.DflProfileEnable(1)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -97,6 +98,19 @@ def run(args, rank, world, local_rank):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     t_total = float(dt.item())
     ms_per_step = 1e3 * t_total / args.steps
+
+    # rank 0's local SpMV against the HBM roofline (owned rows only; same per-unit bytes as the 1-GPU line)
+    tot, mn = C.c_double(0), C.c_double(0)
+    n_spmv = L.DflProfileCollect(0, C.byref(tot), C.byref(mn))
+    L.DflProfileEnable(0)
+    rp, _ = P.pattern()
+    spmv_bytes = 132.0 * float(rp[no]) + 4.0 * (no + 1) + 64.0 * no
+    roofline = None
+    if n_spmv and tot.value > 0:
+        gbps = spmv_bytes * n_spmv / (tot.value * 1e-3) / 1e9
+        roofline = {"kernel": "spmv (rank 0, owned rows)", "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
+                    "frac": gbps / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": spmv_bytes,
+                    "avg_launch_ms": tot.value / n_spmv}
 
     stats = torch.tensor([float(P.T), float(no), float(plan.bytes_per_exchange), float(P.num_color)], dtype=torch.float64,
                          device="cpu" if staged else device)
@@ -118,7 +132,7 @@ def run(args, rank, world, local_rank):
             "redundant_assembly_fraction": sum(r[0] for r in per_rank) / Tg - 1.0,
             "collectives_per_step": {"allreduce": comm.n_allreduce // (args.steps + args.warmup),
                                      "halo_exchange": comm.n_halo // (args.steps + args.warmup)},
-            "roofline": None, "cpu_baseline": None, "setup_s": t_setup,
+            "roofline": roofline, "cpu_baseline": None, "setup_s": t_setup,
             "gmres_residual_drop": float(hist[-1] / r0) if len(hist) else None,
         }
         print(json.dumps(out))
