@@ -55,29 +55,42 @@ def cpu_baseline(M_sample, its):
     m = kuhn_cube(M_sample, jitter=0.2)
     wg, dwg = synthetic_fields(m)
     S = orc.System(m)
-    t0 = time.perf_counter()
-    F, _ = S.assemble_system(wg, dwg, True, False)
-    tF = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    _, vals = S.assemble_system(wg, dwg, False, True)
-    tJ = time.perf_counter() - t0
-    x = np.random.default_rng(0).normal(size=6 * S.N)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        S.matvec(vals, x)
-    tS = (time.perf_counter() - t0) / 5
-    t0 = time.perf_counter()
-    S.gmres(vals, F, maxit=its, atol=0.0, rtol=0.0)
-    tG = time.perf_counter() - t0
-    step = tF + tJ + tG
     spmv_bytes = 132.0 * S.nnz1 + 4.0 * (S.N + 1) + 64.0 * S.N
-    return {
-        "value": 4.0 * S.N / step, "unit": "DOF/s", "cores": 1, "kind": "port",
+    x = np.random.default_rng(0).normal(size=6 * S.N)
+
+    def leg(threads):
+        orc.set_threads(threads)
+        t0 = time.perf_counter()
+        F, _ = S.assemble_system(wg, dwg, True, False)
+        tF = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        _, vals = S.assemble_system(wg, dwg, False, True)
+        tJ = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(5):
+            S.matvec(vals, x)
+        tS = (time.perf_counter() - t0) / 5
+        t0 = time.perf_counter()
+        S.gmres(vals, F, maxit=its, atol=0.0, rtol=0.0)
+        tG = time.perf_counter() - t0
+        step = tF + tJ + tG
+        return {"value": 4.0 * S.N / step, "cores": threads, "assemble_J_s": tJ, "assemble_F_s": tF, "gmres_s": tG, "spmv_s": tS,
+                "assemble_J_dofs_per_s": 4.0 * S.N / tJ, "spmv_GBps": spmv_bytes / tS / 1e9}
+
+    # all host cores of this rank's share (OpenMP over elements-within-color / rows / fixed dot chunks; the
+    # results do not depend on the thread count) and, for reference, one thread
+    ncores = max(1, min(orc.num_procs(), 16))
+    multi = leg(ncores)
+    single = leg(1) if ncores > 1 else dict(multi)
+    orc.set_threads(1)
+    out = dict(multi)
+    out.update({
+        "unit": "DOF/s", "kind": "port",
         "sample": f"Kuhn cube M={M_sample} ({S.T} tets, {S.N} nodes), same step (F + J assembly, {its} GMRES its), "
-                  f"oracle/liboracle.so single thread",
-        "assemble_J_s": tJ, "assemble_F_s": tF, "gmres_s": tG, "spmv_s": tS,
-        "assemble_J_dofs_per_s": 4.0 * S.N / tJ, "spmv_GBps": spmv_bytes / tS / 1e9,
-    }
+                  f"oracle/liboracle.so with OpenMP on {ncores} host threads",
+        "single_thread": single,
+    })
+    return out
 
 
 def main():
@@ -89,6 +102,7 @@ def main():
     ap.add_argument("--gmres-its", type=int, default=40)
     ap.add_argument("--cpu-M", type=int, default=40, help="cube size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--jitter", type=float, default=0.2)
+    ap.add_argument("--dem-particles", type=int, default=100000, help="DEM contact sweep leg after the timed step (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,6 +194,37 @@ def main():
 
     cpu = cpu_baseline(args.cpu_M, its) if args.cpu_M > 0 else None
 
+    # ---- DEM contact sweep (BASELINE config 4 inputs: P = 100k, R = 0.004), outside the timed step ------------
+    dem = None
+    if args.dem_particles > 0:
+        from dedflow_amd.meshgen import dem_particles
+        xp, vp_, R = dem_particles(args.dem_particles, 0.004)
+        pc = api.Particles(xp, vp_, R)
+        pc.compute_forces()
+        api.sync()
+        L.DflProfileEnable(1)
+        tw = time.perf_counter()
+        nrep = 20
+        for _ in range(nrep):
+            pc.compute_forces()
+        api.sync()
+        tw = (time.perf_counter() - tw) / nrep
+        tot, mn = C.c_double(0), C.c_double(0)
+        cnt = L.DflProfileCollect(9, C.byref(tot), C.byref(mn))
+        L.DflProfileEnable(0)
+        kbar = None
+        if args.cpu_M > 0:  # mean neighbours actually tested, from the CPU oracle's cell list (same inputs)
+            from oracle import orc
+            _, tested = orc.dem_forces(xp, vp_, R)
+            kbar = tested / float(args.dem_particles)
+        P_ = float(args.dem_particles)
+        dbytes = (48.0 + 24.0) * P_ + 24.0 * P_ * (kbar if kbar is not None else 0.0)
+        dem = {"particles": args.dem_particles, "radius": R, "sweep_ms_incl_cell_sort": 1e3 * tw,
+               "force_kernel_avg_ms": tot.value / max(cnt, 1), "mean_tested_neighbours": kbar,
+               "force_kernel_GBps": dbytes / (tot.value / max(cnt, 1) * 1e-3) / 1e9 if cnt else None,
+               "particles_per_s": P_ / tw}
+        pc.close()
+
     tJ = kernels.get("asm_lhs", {}).get("total_ms_per_step", 0.0)
     tF = kernels.get("asm_rhs", {}).get("total_ms_per_step", 0.0)
     out = {
@@ -193,7 +238,7 @@ def main():
         "spmv_GBps": kernels.get("spmv", {}).get("GBps"), "spmv_frac_of_hbm_peak": kernels.get("spmv", {}).get("frac_of_8TBps"),
         "assemble_J_dofs_per_s": (4.0 * N / (tJ * 1e-3)) if tJ else None,
         "assemble_F_dofs_per_s": (6.0 * N / (tF * 1e-3)) if tF else None,
-        "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "dem_sweep": dem,
         "setup_s": t_setup, "gmres_residual_drop": float(hist[-1] / r0) if len(hist) else None,
     }
     print(json.dumps(out))

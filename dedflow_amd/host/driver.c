@@ -48,14 +48,34 @@ static void alpha_states(index_type N, const f64* wgold, const f64* dwgold, cons
     HIPGUARD(hipMemsetAsync(wgalpha + (size_t)N * 3, 0, (size_t)N * sizeof(f64), s));
 }
 
-static void four_norms(index_type N, const f64* F, f64* out) {
+static void four_norms(index_type N, const f64* F, f64* out, const DflComm* comm) {
     hipStream_t s = DflStream();
-    dfl_dnrm2(N * 3, F, g_fw.nrm + 0, g_fw.work, s);
-    dfl_dnrm2(N, F + (size_t)N * 3, g_fw.nrm + 1, g_fw.work, s);
-    dfl_dnrm2(N, F + (size_t)N * 4, g_fw.nrm + 2, g_fw.work, s);
-    dfl_dnrm2(N, F + (size_t)N * 5, g_fw.nrm + 3, g_fw.work, s);
+    if (comm) { /* element-partitioned run: ghost entries of F are zero, sums of squares are all-reduced */
+        dfl_ddot(N * 3, F, F, g_fw.nrm + 0, g_fw.work, s);
+        dfl_ddot(N, F + (size_t)N * 3, F + (size_t)N * 3, g_fw.nrm + 1, g_fw.work, s);
+        dfl_ddot(N, F + (size_t)N * 4, F + (size_t)N * 4, g_fw.nrm + 2, g_fw.work, s);
+        dfl_ddot(N, F + (size_t)N * 5, F + (size_t)N * 5, g_fw.nrm + 3, g_fw.work, s);
+        comm->allreduce_sum(comm->ctx, g_fw.nrm, 4);
+    } else {
+        dfl_dnrm2(N * 3, F, g_fw.nrm + 0, g_fw.work, s);
+        dfl_dnrm2(N, F + (size_t)N * 3, g_fw.nrm + 1, g_fw.work, s);
+        dfl_dnrm2(N, F + (size_t)N * 4, g_fw.nrm + 2, g_fw.work, s);
+        dfl_dnrm2(N, F + (size_t)N * 5, g_fw.nrm + 3, g_fw.work, s);
+    }
     HIPGUARD(hipMemcpyAsync(out, g_fw.nrm, 4 * sizeof(f64), D2H, s));
     HIPGUARD(hipStreamSynchronize(s));
+    if (comm) for (int k = 0; k < 4; ++k) out[k] = sqrt(out[k]);
+}
+
+/* partitioned run: residual entries of ghost nodes are partial sums that belong to another rank */
+static void zero_ghost_residual(index_type N, f64* F, const DflComm* comm) {
+    if (!comm) return;
+    const index_type no = comm->num_owned_node;
+    hipStream_t s = DflStream();
+    if (no < N) {
+        HIPGUARD(hipMemsetAsync(F + (size_t)no * 3, 0, (size_t)(N - no) * 3 * sizeof(f64), s));
+        HIPGUARD(hipMemsetAsync(F + (size_t)N * 3 + no, 0, (size_t)(N - no) * sizeof(f64), s));
+    }
 }
 
 /* SolveFlowSystem, main.c:77-283.  Returns the number of Newton iterations; rnorm_out[0..3] / rnorm_init_out[0..3]
@@ -70,10 +90,12 @@ index_type SolveFlowSystem(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matr
     b32 converged = FALSE;
     if (maxit <= 0) maxit = 4;
     fw_ensure(N);
+    const DflComm* comm = KrylovGetComm(ksp);
     f64 *wgalpha = g_fw.wgalpha, *dwgalpha = g_fw.dwgalpha;
     alpha_states(N, wgold, dwgold, dwg, wgalpha, dwgalpha);
     AssembleSystem(mesh, wgalpha, dwgalpha, F, NULL, bcs, nbc);
-    four_norms(N, F, rnorm_init);
+    zero_ghost_residual(N, F, comm);
+    four_norms(N, F, rnorm_init, comm);
     if (!DflQuiet())
         for (int k = 0; k < 4; ++k)
             fprintf(stdout, "Newton %d) abs = %.17e rel = %6.4e (tol = %6.4e)\n", 0, rnorm_init[k], 1.0, tol);
@@ -83,10 +105,12 @@ index_type SolveFlowSystem(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matr
         AssembleSystem(mesh, wgalpha, dwgalpha, NULL, J, bcs, nbc);
         HIPGUARD(hipMemsetAsync(dx, 0, (size_t)N * BS * sizeof(f64), s));
         KrylovSolve(ksp, J, dx, F);
+        if (comm) comm->halo_exchange(comm->ctx, dx); /* ghost copies of the increment from their owners */
         dfl_daxpy(N * BS, -1.0, dx, dwg, s); /* dwg -= dx, main.c:226 */
         alpha_states(N, wgold, dwgold, dwg, wgalpha, dwgalpha);
         AssembleSystem(mesh, wgalpha, dwgalpha, F, NULL, bcs, nbc);
-        four_norms(N, F, rnorm);
+        zero_ghost_residual(N, F, comm);
+        four_norms(N, F, rnorm, comm);
         if (!DflQuiet())
             for (int k = 0; k < 4; ++k)
                 fprintf(stdout, "Newton %d) abs = %.17e rel = %6.4e (tol = %6.4e)\n", iter + 1, rnorm[k], rnorm[k] / rnorm_init[k], tol);

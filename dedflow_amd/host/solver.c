@@ -226,6 +226,7 @@ static Krylov* krylov_init(index_type max_iter, f64 atol, f64 rtol, void* handle
 const KrylovStats* KrylovGetStats(const Krylov* k) { return &kext(k)->stats; }
 void KrylovSetCheckInterval(Krylov* k, index_type n) { kext(k)->check_interval = n > 0 ? n : 20; }
 void KrylovSetVerbose(Krylov* k, b32 v) { kext(k)->verbose = v; }
+const DflComm* KrylovGetComm(const Krylov* k) { return kext(k)->has_comm ? &kext(k)->comm : NULL; }
 void KrylovSetComm(Krylov* k, const DflComm* comm) {
     KrylovExt* x = kext(k);
     x->has_comm = comm != NULL;

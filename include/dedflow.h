@@ -368,6 +368,7 @@ typedef struct DflComm {
     index_type num_owned_node; /* dots / norms run over owned nodes only */
 } DflComm;
 void KrylovSetComm(Krylov* krylov, const DflComm* comm);
+const DflComm* KrylovGetComm(const Krylov* krylov); /* NULL on a single GPU */
 
 /* ---- assembly (assemble.h) ------------------------------------------------------------ */
 void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J);

@@ -513,12 +513,15 @@ void orc_assemble_tet(const f64* xg, const i32* ien, i32 N, i32 num_batch, const
     A.row_ptr = row_ptr; A.col_ind = col_ind;
     A.m[0][0] = A00; A.m[0][1] = A01; A.m[1][0] = A10; A.m[1][1] = A11;
     const bool doJ = (A00 != nullptr);
-    std::vector<f64> elem_J(16 * 36);
     for (i32 b = 0; b < num_batch; ++b) {
         i32 bsz = batch_offset[b + 1] - batch_offset[b];
         if (bsz == 0) break;  // :1565-1567
         const i32* bidx = batch_ind + batch_offset[b];
+        // elements of one color share no node: the loop is race-free and its result independent of the
+        // thread count (cpu_baseline's multi-core leg; orc_set_threads(1) = the serial restatement)
+#pragma omp parallel for schedule(static)
         for (i32 e = 0; e < bsz; ++e) {
+            f64 elem_J[16 * 36];
             i32 iel = bidx[e];
             const i32* nodes = ien + (size_t)iel * 4;
             ElemGeom g;
@@ -539,9 +542,9 @@ void orc_assemble_tet(const f64* xg, const i32* ien, i32 N, i32 num_batch, const
                 }
             }
             if (doJ) {
-                elem_lhs(g, qr_wg, elem_J.data());
+                elem_lhs(g, qr_wg, elem_J);
                 for (int aa = 0; aa < 4; ++aa)
-                    for (int bb = 0; bb < 4; ++bb) scatter_block(A, nodes[aa], nodes[bb], elem_J.data() + (aa * 4 + bb) * 36);
+                    for (int bb = 0; bb < 4; ++bb) scatter_block(A, nodes[aa], nodes[bb], elem_J + (aa * 4 + bb) * 36);
             }
         }
     }
@@ -759,6 +762,7 @@ void orc_dirichlet_mat(i32 n_bnode, const i32* bnode, i32 shape, const i32* bcty
 
 // ---- scalar CSR SpMV y = alpha*A*x + beta*y (cusparseSpMV semantics, matrix.c:101-165)
 void orc_csr_spmv(i32 nrow, const i32* rp, const i32* ci, const f64* val, f64 alpha, const f64* x, f64 beta, f64* y) {
+#pragma omp parallel for schedule(static)
     for (i32 i = 0; i < nrow; ++i) {
         f64 s = 0.0;
         for (i32 j = rp[i]; j < rp[i + 1]; ++j) s += val[j] * x[ci[j]];
@@ -833,6 +837,22 @@ static void drotg(f64* a, f64* b, f64* c, f64* s) {  // reference BLAS drotg (cu
     *a = r; *b = z;
 }
 
+// dot product as a sum of fixed 4096-element chunk sums: the value does not depend on the thread count
+static f64 chunked_dot(const f64* a, const f64* b, size_t n) {
+    const size_t CH = 4096, nch = (n + CH - 1) / CH;
+    std::vector<f64> part(nch);
+#pragma omp parallel for schedule(static)
+    for (long long c = 0; c < (long long)nch; ++c) {
+        size_t lo = (size_t)c * CH, hi = std::min(n, lo + CH);
+        f64 s = 0.0;
+        for (size_t i = lo; i < hi; ++i) s += a[i] * b[i];
+        part[c] = s;
+    }
+    f64 s = 0.0;
+    for (size_t c = 0; c < nch; ++c) s += part[c];
+    return s;
+}
+
 // ---- GMRES: GMRESSolvePrivate, src/krylov.c:56-334 + krylov_util.cu:5-19 --------
 // n = 6N (Q5).  pc_kind: 0 = none (identity), 1 = the reference tree above.
 // res_hist[k] = |beta[k+1]| after iteration k (the reference prints every 20th).
@@ -857,9 +877,7 @@ i32 orc_gmres(i32 N, const i32* rp33, const i32* ci33, const i32* rp31, const i3
 #define HCOL(c) (&H[(size_t)(c) * ldh])
     memcpy(QCOL(0), b, n * sizeof(f64));
     fs_amvpby(P, -1.0, x, 1.0, QCOL(0));
-    f64 rnrm_init = 0.0;
-    for (size_t i = 0; i < n; ++i) rnrm_init += QCOL(0)[i] * QCOL(0)[i];
-    rnrm_init = std::sqrt(rnrm_init);
+    f64 rnrm_init = std::sqrt(chunked_dot(QCOL(0), QCOL(0), n));
     if (rnrm_init_out) *rnrm_init_out = rnrm_init;
     beta[0] = rnrm_init;
     f64 rnrm = 1.0 / rnrm_init;
@@ -870,20 +888,14 @@ i32 orc_gmres(i32 N, const i32* rp33, const i32* ci33, const i32* rp31, const i3
         pc_apply(QCOL(iter), tmp.data());
         fs_amvpby(P, 1.0, tmp.data(), 0.0, QCOL(iter + 1));
         f64* w = QCOL(iter + 1);
-        for (i32 j = 0; j <= iter; ++j) {  // Dgemv OP_T
-            f64 s = 0.0;
-            const f64* q = QCOL(j);
-            for (size_t i = 0; i < n; ++i) s += q[i] * w[i];
-            HCOL(iter)[j] = s;
-        }
+        for (i32 j = 0; j <= iter; ++j) HCOL(iter)[j] = chunked_dot(QCOL(j), w, n);  // Dgemv OP_T
         for (i32 j = 0; j <= iter; ++j) {  // Dgemv OP_N, alpha = -1
             const f64* q = QCOL(j);
             f64 h = HCOL(iter)[j];
-            for (size_t i = 0; i < n; ++i) w[i] -= q[i] * h;
+#pragma omp parallel for schedule(static)
+            for (long long i = 0; i < (long long)n; ++i) w[i] -= q[i] * h;
         }
-        f64 nr = 0.0;
-        for (size_t i = 0; i < n; ++i) nr += w[i] * w[i];
-        nr = std::sqrt(nr);
+        f64 nr = std::sqrt(chunked_dot(w, w, n));
         HCOL(iter)[iter + 1] = nr;
         rnrm = 1.0 / nr;
         for (size_t i = 0; i < n; ++i) w[i] *= rnrm;

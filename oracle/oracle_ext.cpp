@@ -20,6 +20,8 @@ typedef double f64;
 extern "C" {
 
 int orc_num_threads() { return omp_get_max_threads(); }
+int orc_num_procs() { return omp_get_num_procs(); }
+void orc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 
 // OpenMP scalar-CSR SpMV (rows in parallel) -- cpu_baseline only
 void orc_csr_spmv_omp(i32 nrow, const i32* rp, const i32* ci, const f64* val, f64 alpha, const f64* x, f64 beta, f64* y) {

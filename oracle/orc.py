@@ -34,7 +34,16 @@ def lib():
         if not os.path.exists(path):
             build()
         _LIB = C.CDLL(path)
+        _LIB.orc_set_threads(1)  # serial restatement by default; bench.py's cpu_baseline also times all cores
     return _LIB
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def num_procs():
+    return int(lib().orc_num_procs())
 
 
 def _p(a):

@@ -165,11 +165,60 @@ def run_gpu(rank, world, M, its):
     P.close()
 
 
+def run_gpu_step(rank, world, M, its):
+    """One coupled-free time step (predictor, <=2 Newton iterations with distributed GMRES, corrector) on the
+    partitioned mesh against the single-domain oracle driver."""
+    import torch
+    import torch.distributed as dist
+    from dedflow_amd import dist_bench
+    from dedflow_amd import dist as D
+    from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
+    from oracle import orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ref_driver import time_step
+    mesh = kuhn_cube(M, jitter=0.2)
+    Sg = orc.System(mesh)
+    Ng = mesh.num_node
+    wg0, dw0 = synthetic_fields(mesh)
+    wgold = wg0.copy()
+    wgold[3 * Ng:4 * Ng] = 0.0
+    dwgold = 0.1 * dw0
+    dwg = dwgold.copy()
+    it_o, rn_o, ri_o, wgold_o, dwgold_o, _ = time_step(Sg, wgold, dwgold, dwg, maxit=2)
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    lm, alloc, P, plan, comm = dist_bench.setup_rank(mesh, rank, world, device, dist, 120, True)
+    from dedflow_amd import api
+    api.lib().KrylovDestroy(P.ksp)  # reference solver settings for the driver: GMRES(120), atol 1e-12, rtol 1e-4
+    P.ksp = api.lib().KrylovCreateGMRES(120, 1e-12, 1e-4, None)
+    api.lib().KrylovSetVerbose(P.ksp, 0)
+    comm.install(P.ksp)
+    n, no = P.N, lm.n_owned
+    vecs = [dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(v, lm, Ng)) for v in (wgold, dwgold, dwg)]
+    F_t, F_p = dist_bench.device_vector(alloc, torch, device, 6 * n)
+    dx_t, dx_p = dist_bench.device_vector(alloc, torch, device, 6 * n)
+    Pp = dist_bench._Ptr
+    it, rn, ri = P.time_step(Pp(vecs[0][1]), Pp(vecs[1][1]), Pp(vecs[2][1]), Pp(F_p), Pp(dx_p), newton_maxit=2)
+    torch.cuda.synchronize()
+    assert it == it_o
+    assert np.allclose(ri, ri_o, rtol=1e-9, atol=1e-10 * ri_o.max()), (ri, ri_o)
+    assert np.allclose(rn, rn_o, rtol=1e-5, atol=1e-8 * ri_o.max()), (rn, rn_o)
+    # every local node (owned AND ghost copies) carries the global state
+    for (t, _), ref in zip(vecs[:2], (wgold_o, dwgold_o)):
+        loc = t.cpu().numpy()
+        exp = D.localize_vector(ref, lm, Ng)
+        assert np.abs(loc - exp).max() <= 1e-7 * np.abs(ref).max(), np.abs(loc - exp).max()
+    dist.barrier()
+    if rank == 0:
+        print("DIST_STEP_OK", world, it)
+    P.close()
+
+
 if __name__ == "__main__":
     import torch.distributed as dist
     mode, M, its = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    (run_cpu if mode == "cpu" else run_gpu)(rank, world, M, its)
+    {"cpu": run_cpu, "gpu": run_gpu, "gpu_step": run_gpu_step}[mode](rank, world, M, its)
     dist.barrier()
     dist.destroy_process_group()

@@ -42,3 +42,11 @@ def test_distributed_algorithm_cpu_gloo(world, oracle_lib):
 def test_distributed_product_path_gpu_gloo(world, oracle_lib):
     out = _launch("gpu", world, 8, 30)
     assert "DIST_GPU_OK" in out
+
+
+@pytest.mark.gpu
+def test_distributed_time_step_gpu_gloo(oracle_lib):
+    """SolveFlowSystem / DflTimeStep on a 2-way partition: ghost residual zeroing, all-reduced Newton norms,
+    halo exchange of the Newton increment."""
+    out = _launch("gpu_step", 2, 6, 0)
+    assert "DIST_STEP_OK" in out
