@@ -6,7 +6,7 @@ CC      ?= gcc
 ARCH    ?= gfx950
 ROCM    ?= /opt/rocm
 HIPFLAGS = -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Iinclude
-CFLAGS   = -O2 -std=gnu99 -fPIC -Wall -Wno-unused-function -D__HIP_PLATFORM_AMD__ -Iinclude -I$(ROCM)/include -Idedflow_amd/host
+CFLAGS   = -O2 -std=gnu99 -fPIC -fopenmp -Wall -Wno-unused-function -D__HIP_PLATFORM_AMD__ -Iinclude -I$(ROCM)/include -Idedflow_amd/host
 
 KSRC = $(wildcard dedflow_amd/csrc/*.hip)
 HSRC = $(wildcard dedflow_amd/host/*.c)
@@ -34,7 +34,7 @@ dedflow_amd/host/%.o: dedflow_amd/host/%.c include/dedflow.h include/dedflow_ker
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(LIB): $(KOBJ) $(HOBJ)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^
+	$(HIPCC) -shared -fPIC -fopenmp --offload-arch=$(ARCH) -o $@ $^
 
 oracle:
 	$(MAKE) -C oracle

@@ -110,46 +110,37 @@ constexpr int EPB = 16;
 constexpr int LBLK = 256;
 constexpr int TRS = 257;  // padded row length of the transpose buffer
 
-__global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict__ ien_b, const I* __restrict__ nzmap_b,
-                                                      const T* __restrict__ nodep, T* __restrict__ val) {
-    __shared__ double s_x[EPB][12];
-    __shared__ double s_u[EPB][12];
-    __shared__ double s_shg[EPB][12];
-    __shared__ double s_conv[EPB][4][4];  // [a][q]
-    __shared__ double s_tau[EPB][4][2];   // [q][tauM, tauC]
-    __shared__ double s_scal[EPB][4];     // detJ, gg, 1/tr
-    __shared__ double s_blk[16 * TRS];
-    __shared__ int s_nz[LBLK];
+// per-element staging shared by the 16 lanes of an element (all inside one wave)
+struct LhsStage {
+    double u[EPB][12];
+    double shg[EPB][12];
+    double conv[EPB][4][4];  // [a][q]
+    double tau[EPB][4][2];   // [q][tauM, tauC]
+    double scal[EPB][4];     // detJ, gg, 1/tr
+};
 
-    const int t = threadIdx.x;
-    const int te = t >> 4, p = t & 15;
-    const long long e = (long long)blockIdx.x * EPB + te;
-    const bool valid = e < B;
-
-    s_nz[t] = valid ? nzmap_b[(long long)blockIdx.x * LBLK + t] : -1;
-    if (valid && p < 12) {
-        const int a = p / 3, d = p - a * 3;
-        const long long node = ien_b[e * 4 + a];
-        s_x[te][p] = nodep[node * 16 + d];      // packed node record: x at [0..2], u at [3..5]
-        s_u[te][p] = nodep[node * 16 + 3 + d];
-    }
-    WAVE_SYNC();
-
-    if (valid && p == 0) {
-        double invJ[9], shg[12], G[9], detJ;
-        tet_geometry(s_x[te], invJ, detJ, shg);
-        tet_metric(shg, G);
-        double gg = 0.0, tr = 0.0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {  // :528-533
-            gg += G[i] * G[i];
-            if (!(i & 3)) tr += G[i];
+// The 4x4 (u,p) block of node pair (a,b) = (p>>2, p&3) of one tet: gather, geometry, convection at the 4
+// quadrature points, stabilisation parameters, block.  `nodes` = the element's 4 node ids.
+// `egeo` = the element's cached geometry record (elem_geometry_kernel: shg[12], detJ, gg, 1/tr, pad), read as
+// one coalesced 128-byte line by the element's 16 lanes -- the mesh does not move inside the time loop, so the
+// Jacobian inverse / shape gradients / metric are computed once per mesh instead of once per assembly.
+__device__ __forceinline__ void lhs_element_block(LhsStage& S, int te, int p, bool valid, const I* __restrict__ nodes,
+                                                  const T* __restrict__ egeo, const T* __restrict__ nodep, double* Bk) {
+    double (*s_u)[12] = S.u;
+    double (*s_shg)[12] = S.shg;
+    double (*s_conv)[4][4] = S.conv;
+    double (*s_tau)[4][2] = S.tau;
+    double (*s_scal)[4] = S.scal;
+    if (valid) {
+        const double g = egeo[p];
+        if (p < 12) {
+            const int a = p / 3, d = p - a * 3;
+            const long long node = nodes[a];
+            s_shg[te][p] = g;
+            s_u[te][p] = nodep[node * 16 + 3 + d];  // packed node record: u at [3..5]
+        } else {
+            s_scal[te][p - 12] = g;  // detJ, gg, 1/tr, pad
         }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) s_shg[te][i] = shg[i];
-        s_scal[te][0] = detJ;
-        s_scal[te][1] = gg;
-        s_scal[te][2] = 1.0 / tr;
     }
     WAVE_SYNC();
 
@@ -183,7 +174,6 @@ __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict_
     }
     WAVE_SYNC();
 
-    double Bk[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) Bk[i] = 0.0;
     if (valid) {
@@ -244,6 +234,23 @@ __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict_
         }
         Bk[15] = w * S_t0 * eK;  // dRC/dP
     }
+}
+
+__global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict__ ien_b, const I* __restrict__ nzmap_b,
+                                                      const T* __restrict__ egeo, const T* __restrict__ nodep,
+                                                      T* __restrict__ val) {
+    __shared__ LhsStage S;
+    __shared__ double s_blk[16 * TRS];
+    __shared__ int s_nz[LBLK];
+
+    const int t = threadIdx.x;
+    const int te = t >> 4, p = t & 15;
+    const long long e = (long long)blockIdx.x * EPB + te;
+    const bool valid = e < B;
+
+    s_nz[t] = valid ? nzmap_b[(long long)blockIdx.x * LBLK + t] : -1;
+    double Bk[16];
+    lhs_element_block(S, te, p, valid, ien_b + (valid ? e : 0) * 4, egeo + (valid ? e : 0) * 16, nodep, Bk);
     // transpose through LDS: s_blk[i][t] = entry i of the block owned by thread t
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_blk[i * TRS + t] = Bk[i];
@@ -268,6 +275,72 @@ __global__ __launch_bounds__(LBLK) void tet_lhs_kernel(I B, const I* __restrict_
             nv.x = oldv[pass].x + s_blk[(2 * l8) * TRS + bi];
             nv.y = oldv[pass].y + s_blk[(2 * l8 + 1) * TRS + bi];
             *reinterpret_cast<double2*>(val + addr[pass]) = nv;
+        }
+    }
+}
+
+// ====================================================================================
+//  LHS, patch form (assembly schedule 2; host/patch.c).  One workgroup owns one spatial patch
+//  of tets: every (a,b) block contribution is summed into an LDS table indexed by the patch's
+//  local block slots (LDS f64 atomics: ds_add_f64), and each distinct block of the patch is
+//  read-modify-written in HBM once per patch instead of once per tet.  Patches of one launch
+//  share no node (patch coloring), so the global RMW needs no atomics.
+//  LDS table layout: entry-major, tab[i * NS + slot] (NS odd), so the 8 lanes that flush one
+//  block line read 8 different banks.
+// ====================================================================================
+__global__ __launch_bounds__(LBLK) void tet_lhs_patch_kernel(const I* __restrict__ p_eoff, const I* __restrict__ p_boff,
+                                                            I patch_base, const I* __restrict__ ien_p,
+                                                            const unsigned short* __restrict__ lslot,
+                                                            const I* __restrict__ blk_nz, const T* __restrict__ egeo,
+                                                            const T* __restrict__ nodep, T* __restrict__ val, int NS, int dbg) {
+    extern __shared__ double dyn_lds[];
+    __shared__ LhsStage S;
+    double* tab = dyn_lds;  // [16][NS]
+    const int t = threadIdx.x;
+    const int te = t >> 4, p = t & 15;
+    const int patch = patch_base + blockIdx.x;
+    const int e0 = p_eoff[patch], ne = p_eoff[patch + 1] - e0;
+    const int b0 = p_boff[patch], nb = p_boff[patch + 1] - b0;
+    for (int i = t; i < 16 * NS; i += LBLK) tab[i] = 0.0;
+    __syncthreads();
+    for (int base = 0; base < ((dbg & 1) ? 0 : ne); base += EPB) {
+        const int le = base + te;
+        const bool valid = le < ne;
+        const long long e = e0 + (valid ? le : 0);
+        double Bk[16];
+        WAVE_SYNC();  // the wave's staging slots are about to be overwritten
+        lhs_element_block(S, te, p, valid, ien_p + e * 4, egeo + e * 16, nodep, Bk);
+        if (valid) {
+            const int slot = lslot[e * 16 + p];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) if (!(dbg & 4)) atomicAdd(&tab[i * NS + slot], Bk[i]); else if (Bk[i] == 1.2345e300) tab[i] = 1.0;
+        }
+    }
+    __syncthreads();
+    // flush: 8 lanes per block line, 32 lines per pass, 4 passes in flight
+    const int l8 = t & 7;
+    if (dbg & 2) return;
+    for (int s0 = t >> 3; s0 < nb; s0 += 32 * 4) {
+        double2 oldv[4];
+        long long addr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s = s0 + 32 * k;
+            addr[k] = -1;
+            if (s < nb) {
+                addr[k] = (long long)blk_nz[b0 + s] * 16 + 2 * l8;
+                oldv[k] = *reinterpret_cast<const double2*>(val + addr[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s = s0 + 32 * k;
+            if (addr[k] >= 0) {
+                double2 nv;
+                nv.x = oldv[k].x + tab[(2 * l8) * NS + s];
+                nv.y = oldv[k].y + tab[(2 * l8 + 1) * NS + s];
+                *reinterpret_cast<double2*>(val + addr[k]) = nv;
+            }
         }
     }
 }
@@ -685,6 +758,34 @@ __global__ __launch_bounds__(64) void face_kernel(I nf, const I* __restrict__ fa
     }
 }
 
+// per-element geometry cache for the LHS kernels: shg[12], detJ, gg = sum G_ij^2, 1/trace(G), pad
+// (GetElemInvJ3D + GetShapeGradKernel + metric gemm + the gg/tr prologue of assemble.cu:528-535)
+__global__ __launch_bounds__(256) void elem_geometry_kernel(I T_, const I* __restrict__ ien_x, const T* __restrict__ xg,
+                                                           T* __restrict__ egeo) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= T_) return;
+    double x[12];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long long n = ien_x[e * 4 + a];
+        x[a * 3] = xg[3 * n]; x[a * 3 + 1] = xg[3 * n + 1]; x[a * 3 + 2] = xg[3 * n + 2];
+    }
+    double invJ[9], shg[12], G[9], detJ;
+    tet_geometry(x, invJ, detJ, shg);
+    tet_metric(shg, G);
+    double gg = 0.0, tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        gg += G[i] * G[i];
+        if (!(i & 3)) tr += G[i];
+    }
+    double2* o = reinterpret_cast<double2*>(egeo + e * 16);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = make_double2(shg[2 * k], shg[2 * k + 1]);
+    o[6] = make_double2(detJ, gg);
+    o[7] = make_double2(1.0 / tr, 0.0);
+}
+
 __global__ __launch_bounds__(256) void nzmap_kernel(I T_, const I* __restrict__ ien_b, const I* __restrict__ rp,
                                                    const I* __restrict__ ci, I* __restrict__ nzmap) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -705,9 +806,27 @@ __global__ __launch_bounds__(256) void gather_ien_kernel(I T_, const I* __restri
 
 extern "C" {
 
-void dfl_assemble_tet_lhs(I B, const I* ien_b, const I* nzmap_b, const T* nodep, T* val, void* stream) {
+int g_patch_dbg = 0;
+void dfl_tune_asm(int v) { g_patch_dbg = v; }
+void dfl_elem_geometry(I T_, const I* ien_x, const T* xg, T* egeo, void* stream) {
+    if (T_ <= 0) return;
+    elem_geometry_kernel<<<ceil_div(T_, 256), 256, 0, S(stream)>>>(T_, ien_x, xg, egeo);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_assemble_tet_lhs(I B, const I* ien_b, const I* nzmap_b, const T* egeo_b, const T* nodep, T* val, void* stream) {
     if (B <= 0) return;
-    tet_lhs_kernel<<<ceil_div(B, EPB), LBLK, 0, S(stream)>>>(B, ien_b, nzmap_b, nodep, val);
+    tet_lhs_kernel<<<ceil_div(B, EPB), LBLK, 0, S(stream)>>>(B, ien_b, nzmap_b, egeo_b, nodep, val);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_assemble_tet_lhs_patch(I npatch, I patch_base, const I* p_eoff, const I* p_boff, const I* ien_p,
+                                const unsigned short* lslot, const I* blk_nz, const T* egeo_p, const T* nodep, T* val,
+                                I max_slots, void* stream) {
+    if (npatch <= 0) return;
+    const int NS = (int)max_slots | 1;  // odd stride: conflict-free flush reads
+    const size_t shmem = (size_t)16 * NS * sizeof(double);
+    tet_lhs_patch_kernel<<<npatch, LBLK, shmem, S(stream)>>>(p_eoff, p_boff, patch_base, ien_p, lslot, blk_nz, egeo_p, nodep, val, NS, g_patch_dbg);
     DFL_LAUNCH_CHECK();
 }
 

@@ -9,6 +9,13 @@
 
 #define BS (6)
 static b32 g_quiet = FALSE;
+/* patch schedule tunables: tets per patch before the LDS-slot cap applies, and that cap
+ * (16 * (cap|1) * 8 B of dynamic LDS per workgroup; 448 -> 57.5 KB -> two workgroups per CU) */
+static index_type g_patch_leaf = 96, g_patch_cap = 448;
+void DflSetPatchParameters(index_type leaf, index_type slot_cap) {
+    if (leaf > 0) g_patch_leaf = leaf;
+    if (slot_cap > 0 && slot_cap <= 511) g_patch_cap = slot_cap;
+}
 void DflSetQuiet(b32 quiet) { g_quiet = quiet; }
 b32 DflQuiet(void) { return g_quiet; }
 
@@ -44,7 +51,7 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
     const CSRAttr* spy = NULL;
     if (J) {
         spy = block_pattern(J, &val);
-        ensure_nzmap(mesh, spy);
+        if (DflAssemblyScheduleMode() != 2) ensure_nzmap(mesh, spy);
     }
     /* packed gather records (one line per node) and packed residual accumulator */
     if (!x->nodep) {
@@ -52,6 +59,11 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
         x->Fp = (f64*)CdamMallocDevice((ptrdiff_t)N * 8 * SIZE_OF(f64));
     }
     dfl_pack_nodes(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, x->nodep, s);
+    const b32 patch_lhs = J && DflAssemblyScheduleMode() == 2;
+    if (J && !patch_lhs && !x->egeo_b) { /* geometry cache in schedule order (static mesh), built once */
+        x->egeo_b = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
+        dfl_elem_geometry(mesh->num_tet, x->ien_b, dev->xg, x->egeo_b, s);
+    }
     /* one launch per class of the execution schedule (mesh.c: the reference's color batches in
        mode 0, the compact re-coloring otherwise) */
     for (index_type b = 0; b < x->sched_num; ++b) {
@@ -60,7 +72,27 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
         if (bsz == 0) continue;
         const index_type* ien_b = x->ien_b + (size_t)off * 4;
         if (F) DFL_TIMED(DFL_TAG_ASM_RHS, dfl_assemble_tet_rhs(bsz, ien_b, x->nodep, x->Fp, s));
-        if (J) DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, x->nodep, val, s));
+        if (J && !patch_lhs)
+            DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, x->egeo_b + (size_t)off * 16,
+                                                            x->nodep, val, s));
+    }
+    if (patch_lhs) { /* schedule 2: one launch per PATCH color, each block RMW'd once per patch (host/patch.c) */
+        if (x->patch && x->patch->attr != spy) {
+            DflFreePatchSchedule(x->patch);
+            x->patch = NULL;
+        }
+        if (!x->patch) {
+            x->patch = DflBuildPatchSchedule(mesh, spy, g_patch_leaf, g_patch_cap);
+            x->patch->d_egeo = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
+            dfl_elem_geometry(mesh->num_tet, x->patch->d_ien, dev->xg, x->patch->d_egeo, s);
+        }
+        const PatchSched* ps = x->patch;
+        for (index_type c = 0; c < ps->num_color; ++c) {
+            const index_type p0 = ps->color_offset[c], np = ps->color_offset[c + 1] - p0;
+            if (!np) continue;
+            DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_patch(np, p0, ps->d_eoff, ps->d_boff, ps->d_ien, ps->d_lslot,
+                                                                  ps->d_blk_nz, ps->d_egeo, x->nodep, val, ps->max_slots, s));
+        }
     }
     if (F) dfl_unpack_rhs(N, x->Fp, F, s);
 }

@@ -3,6 +3,23 @@
 #define DFL_HOST_PRIVATE_H
 #include "dedflow.h"
 
+/* Patch schedule of the LHS assembly (host/patch.c): spatial patches of <= leaf tets whose (row,col)
+ * blocks fit an LDS table; patches of one color share no node. */
+typedef struct PatchSched {
+    const CSRAttr* attr;       /* pattern the slot maps were built for */
+    index_type num_patch, num_color, max_slots;
+    index_type* color_offset;  /* host [num_color+1], patches sorted by color */
+    index_type* d_eoff;        /* device [num_patch+1] element offsets (patch order) */
+    index_type* d_boff;        /* device [num_patch+1] block-slot offsets */
+    index_type* d_ien;         /* device [T][4] connectivity in patch order */
+    uint16_t* d_lslot;         /* device [T][16] LDS slot of each (elem,a,b) block */
+    index_type* d_blk_nz;      /* device [sum slots] nodal nonzero of each slot */
+    f64* d_egeo;               /* device [T][16] element geometry cache in patch order */
+    int64_t total_slots;
+} PatchSched;
+PatchSched* DflBuildPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap);
+void DflFreePatchSchedule(PatchSched* ps);
+
 typedef struct MeshExt {
     index_type* ien_b;             /* device [T][4], elements in execution-schedule order */
     index_type sched_num;          /* number of conflict-free launches of the execution schedule */
@@ -14,8 +31,10 @@ typedef struct MeshExt {
     index_type* face_color_offset; /* host [face_num_class+1] */
     index_type face_num_class;     /* conflict-free face classes (greedy node coloring of the group's faces) */
     index_type* h_f2e;             /* host copy of bound_f2e */
+    f64* egeo_b;                   /* device [T][16] element geometry cache in schedule order (LHS kernel) */
     f64* nodep;                    /* device [N][16] packed gather records (x,u,phi,T,du,p,dphi,dT) */
     f64* Fp;                       /* device [N][8] packed residual accumulator, zero between calls */
+    PatchSched* patch;             /* LHS patch schedule (assembly schedule mode 2), built on first use */
 } MeshExt;
 
 void DflMeshPrepareFaces(Mesh3D* mesh, index_type group);

@@ -91,6 +91,8 @@ void Mesh3DDestroy(Mesh3D* m) {
     if (x) {
         CdamFreeDevice(x->ien_b, 0);
         CdamFreeDevice(x->nzmap_b, 0);
+        DflFreePatchSchedule(x->patch);
+        CdamFreeDevice(x->egeo_b, 0);
         CdamFreeDevice(x->nodep, 0);
         CdamFreeDevice(x->Fp, 0);
         CdamFreeDevice(x->face_list, 0);

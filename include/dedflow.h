@@ -392,6 +392,10 @@ void DflSetQuiet(b32 quiet); /* suppress the reference's stdout chatter ("Assemb
  *   1  (default) compact balanced re-coloring, ~4x fewer / larger launches; mesh->color,
  *      batch_offset and batch_ind are the reference's JPL result in both modes */
 void DflSetAssemblySchedule(int mode);
+/*   2  as 1 for the RHS; the Jacobian is assembled patch-wise: one workgroup sums all blocks of a spatial
+ *      patch of tets in LDS and read-modify-writes each distinct block once per patch (host/patch.c) --
+ *      ~3x less HBM traffic than one RMW per tet; LDS atomics => values reproducible to rounding, not bitwise */
+void DflSetPatchParameters(index_type leaf, index_type slot_cap);
 
 /* ---- arrays / particles (Array.h, Particle.h) ------------------------------------------ */
 typedef struct Array {

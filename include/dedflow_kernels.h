@@ -189,9 +189,21 @@ dfl_index dfl_count_priority_ties(const dfl_index* ien, dfl_index T, const dfl_i
 void dfl_pack_nodes(dfl_index N, const dfl_value* xg, const dfl_value* wgalpha, const dfl_value* dwgalpha /*or NULL*/,
                     dfl_value* nodep /*[N][16]*/, void* stream);
 void dfl_unpack_rhs(dfl_index N, dfl_value* Fp /*[N][8], zeroed on return*/, dfl_value* F, void* stream);
-void dfl_assemble_tet_lhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_index* nzmap_b, const dfl_value* nodep,
-                          dfl_value* val, void* stream);
+/* per-element geometry cache (static mesh): egeo[e*16 + ..] = shape gradients[12], |det J|, sum G_ij^2, 1/tr G, pad;
+ * `ien_x` is the connectivity in the order the consuming kernel walks (schedule or patch order) */
+void dfl_elem_geometry(dfl_index T, const dfl_index* ien_x, const dfl_value* xg, dfl_value* egeo, void* stream);
+void dfl_assemble_tet_lhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_index* nzmap_b, const dfl_value* egeo_b,
+                          const dfl_value* nodep, dfl_value* val, void* stream);
 void dfl_assemble_tet_rhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_value* nodep, dfl_value* Fp, void* stream);
+/* patch form of the LHS assembly (assembly schedule 2): one workgroup per spatial patch of tets sums all
+ * (a,b) blocks of the patch in an LDS table (ds_add_f64) and read-modify-writes each distinct block once.
+ * Launch = the `npatch` patches [patch_base, patch_base+npatch) of one patch color (no shared nodes).
+ * p_eoff/p_boff: per-patch element / block-slot offsets; ien_p: connectivity in patch order;
+ * lslot[e*16 + a*4+b]: LDS slot of each block; blk_nz: nodal nonzero of each slot; max_slots <= 511. */
+void dfl_assemble_tet_lhs_patch(dfl_index npatch, dfl_index patch_base, const dfl_index* p_eoff, const dfl_index* p_boff,
+                                const dfl_index* ien_p, const unsigned short* lslot, const dfl_index* blk_nz,
+                                const dfl_value* egeo_p, const dfl_value* nodep, dfl_value* val, dfl_index max_slots,
+                                void* stream);
 /* weak-BC faces of one color (src/assemble.cu:1764-1964): face list entries index f2e/forn of the group */
 void dfl_assemble_face(dfl_index n_face, const dfl_index* face_list, const dfl_index* f2e, const dfl_index* forn,
                        const dfl_index* ien, dfl_index N, const dfl_value* xg, const dfl_value* wgalpha,

@@ -268,7 +268,7 @@ def test_reference_color_schedule_matches_compact_schedule(api, oracle_lib):
     wg, dwg = synthetic_fields(m)
     F, vals = S.assemble_system(wg, dwg, True, True)
     out = []
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         P = api.Problem(m, schedule=mode)
         try:
             assert np.array_equal(P.color(), S.color) and np.array_equal(P.batch_ind(), S.batch_ind)

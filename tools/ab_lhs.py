@@ -1,0 +1,43 @@
+"""A/B of the Jacobian-assembly schedules (1 = compact colors, 2 = patch/LDS) at M (default 119)."""
+import ctypes as C, sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dedflow_amd import api
+from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 119
+configs = [(1, 0, 0)] + [(2, int(a), int(b)) for a, b in (c.split(":") for c in sys.argv[2:])] if len(sys.argv) > 2 else [(1, 0, 0), (2, 96, 448)]
+mesh = kuhn_cube(M, jitter=0.2)
+wg, dwg = synthetic_fields(mesh)
+L = api.lib()
+ref = None
+for mode, leaf, cap in configs:
+    if mode == 2:
+        L.DflSetPatchParameters(leaf, cap)
+    t0 = time.perf_counter()
+    P = api.Problem(mesh, schedule=mode)
+    wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+    L.MatrixZero(P.J)
+    P.assemble_tet(wg_d, dwg_d, None, want_J=True)   # builds the schedule on first use
+    api.sync()
+    t_setup = time.perf_counter() - t0
+    t = api.Timer()
+    res = []
+    for rep in range(5):
+        L.MatrixZero(P.J)
+        api.sync()
+        t.start()
+        P.assemble_tet(wg_d, dwg_d, None, want_J=True)
+        t.stop()
+        res.append(t.ms())
+    L.MatrixZero(P.J)
+    P.assemble_tet(wg_d, dwg_d, None, want_J=True)
+    api.sync()
+    v = P.block_values().numpy()
+    if ref is None:
+        ref = v
+    err = np.abs(v - ref).max() / np.abs(ref).max()
+    ms = float(np.median(res))
+    print("mode %d leaf %d cap %d: J assembly median %.3f ms (min %.3f)  %.3g DOF/s  setup %.1f s  rel diff vs mode 1: %.2e" %
+          (mode, leaf, cap, ms, min(res), 4.0 * P.N / (ms * 1e-3), t_setup, err), flush=True)
+    P.close()
