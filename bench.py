@@ -39,7 +39,11 @@ def algorithmic_bytes(N, T, nnz1, its):
     n4 = 4 * N
     return {
         "spmv": 132.0 * nnz1 + 4.0 * (N + 1) + 64.0 * N,                      # per matvec
-        "asm_lhs": T * (16.0 + 4.0 + 4096.0) + 120.0 * N,                    # per J assembly (all colors)
+        # per J assembly, row-owner schedule: every block line written once + slot map, per tet
+        # connectivity + geometry record + 4 items x 12 B, one packed record per node.  (The reference's
+        # colored scatter, SURVEY 8(d), is 4116*T + 120*N: every block line read+written once per tet.)
+        "asm_lhs": 132.0 * nnz1 + T * (16.0 + 128.0 + 48.0) + 128.0 * N,
+        "asm_lhs_colored": T * (16.0 + 4.0 + 4096.0) + 120.0 * N,
         "asm_rhs": T * (20.0 + 384.0) + 120.0 * N,                           # per F assembly
         "pc_apply": (9 + 1) * 8.0 * N + 2 * 8.0 * n4,                        # per apply
         "cgs": [2 * 8.0 * n4 * (k + 1) + 24.0 * n4 for k in range(its)],     # dots+update of step k
@@ -167,7 +171,8 @@ def main():
                          "frac_of_8TBps": gbps / HBM_PEAK_GBS, "bytes": unit_desc}
 
     c, t, _ = prof["spmv"]; entry("spmv", ab["spmv"] * c, c, t, "132*nnz1+4(N+1)+64N per launch")
-    c, t, _ = prof["asm_lhs"]; entry("asm_lhs", ab["asm_lhs"] * K, c, t, "4116*T+120N per J assembly (one launch per color)")
+    c, t, _ = prof["asm_lhs"]; entry("asm_lhs", ab["asm_lhs"] * K, c, t, "132*nnz1+192*T+128N per J assembly (row-owner patches, one launch; "
+                                                                      "the colored scatter of SURVEY 8(d) would move 4116*T+120N)")
     c, t, _ = prof["asm_rhs"]; entry("asm_rhs", ab["asm_rhs"] * K, c, t, "404*T+120N per F assembly (one launch per color)")
     c, t, _ = prof["pc_apply"]; entry("pc_apply", ab["pc_apply"] * c, c, t, "80N+64N per apply")
     cd, td, _ = prof["cgs_dots"]; cu, tu, _ = prof["cgs_update"]

@@ -256,6 +256,7 @@ def _declare(L):
     f("Init", None, [C.c_int, vp]); f("Finalize", None, [])
     f("DflStream", vp, []); f("DflSetStream", None, [vp]); f("DflSetQuiet", None, [i32])
     f("DflSetAssemblySchedule", None, [C.c_int]); f("DflSetPatchParameters", None, [i32, i32])
+    f("DflSetRowPatchParameters", None, [i32, i32]); f("dfl_tune_asm", None, [C.c_int])
     f("Mesh3DCreate", C.POINTER(Mesh3D), [i32, i32, i32, i32]); f("Mesh3DDestroy", None, [C.POINTER(Mesh3D)])
     f("Mesh3DUpdateDevice", None, [C.POINTER(Mesh3D)]); f("Mesh3DGenerateColorBatch", None, [C.POINTER(Mesh3D)])
     f("Mesh3DSetBound", None, [C.POINTER(Mesh3D), i32, vp, vp, vp, vp, vp])
@@ -309,7 +310,7 @@ REFERENCE_BCS = [(0, (1, 1, 1)), (2, (0, 1, 0)), (3, (0, 0, 1)), (4, (0, 0, 0))]
 class Problem:
     """The reference driver's setup sequence (src/main.c:362-477) through the C API."""
 
-    def __init__(self, mesh, maxit=120, atol=1e-12, rtol=1e-4, quiet=True, bcs=REFERENCE_BCS, color=True, schedule=1):
+    def __init__(self, mesh, maxit=120, atol=1e-12, rtol=1e-4, quiet=True, bcs=REFERENCE_BCS, color=True, schedule=3):
         L = lib()
         L.Init(0, None)
         L.DflSetQuiet(1 if quiet else 0)

@@ -110,6 +110,60 @@ constexpr int EPB = 16;
 constexpr int LBLK = 256;
 constexpr int TRS = 257;  // padded row length of the transpose buffer
 
+// The 4x4 (u,p) block of node pair (aa,bb) from the shape gradients of the two nodes, |det J| and the
+// per-quadrature-point stabilisation parameters / convective shape derivatives (assemble.cu:618-661).
+// Every term of the reference's per-quadrature-point update is (quadrature-dependent scalar) x
+// (quadrature-independent geometry product) x detJ*gw with equal weights, so the 4-point loop reduces to
+// eleven scalar sums followed by ONE pass over the 16 block entries: ~5x fewer fp64 operations than the
+// literal loop.  Same terms, different association: results differ from the oracle by rounding only
+// (tests bound it at 1e-10).
+__device__ __forceinline__ void lhs_block_eval(int aa, int bb, const double* ga, const double* gb, double detJ,
+                                               const double* t0, const double* t1, const double* cav,
+                                               const double* cbv, double* Bk) {
+    const double fact1 = kALPHAM;
+    const double fact2 = kDT * kALPHAF * kGAMMA;
+    const double eK = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+    double S_t0 = 0.0, S_t1 = 0.0, S_sa = 0.0, S_sb = 0.0, S_sasb = 0.0, S_t0ca = 0.0, S_t0casb = 0.0, S_sacb = 0.0,
+           S_t0cacb = 0.0, S_t0sb = 0.0, S_t0cb = 0.0;
+#pragma unroll
+    for (int iq = 0; iq < 4; ++iq) {
+        const double tau0 = t0[iq], tau1 = t1[iq];
+        const double ca = cav[iq], cb = cbv[iq];
+        const double sa = shl(aa, iq), sb = shl(bb, iq);
+        const double t0ca = tau0 * ca;
+        S_t0 += tau0;
+        S_t1 += tau1;
+        S_sa += sa;
+        S_sb += sb;
+        S_sasb += sa * sb;
+        S_t0ca += t0ca;
+        S_t0casb += t0ca * sb;
+        S_sacb += sa * cb;
+        S_t0cacb += t0ca * cb;
+        S_t0sb += tau0 * sb;
+        S_t0cb += tau0 * cb;
+    }
+    const double w = detJ * GW;
+    const double diag = w * (fact1 * kRHO * S_sasb + fact1 * kRHO * kRHO * S_t0casb + fact2 * kRHO * S_sacb +
+                             fact2 * kRHO * kRHO * S_t0cacb + 4.0 * fact2 * kMU * eK);
+    const double cK = 4.0 * fact2 * kMU * w, cT = fact2 * kRHO * S_t1 * w;
+#pragma unroll
+    for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) Bk[ii * 4 + jj] = cK * ga[jj] * gb[ii] + cT * ga[ii] * gb[jj];
+    Bk[0] += diag;
+    Bk[5] += diag;
+    Bk[10] += diag;
+    const double cP0 = w * S_sb, cP1 = w * kRHO * S_t0ca;
+    const double cU0 = w * (fact1 * kRHO * S_t0sb + fact2 * kRHO * S_t0cb), cU1 = w * fact2 * S_sa;
+#pragma unroll
+    for (int ii = 0; ii < 3; ++ii) {
+        Bk[ii * 4 + 3] = cP1 * gb[ii] - cP0 * ga[ii];  // dRM/dP
+        Bk[12 + ii] = cU0 * ga[ii] + cU1 * gb[ii];     // dRC/dU
+    }
+    Bk[15] = w * S_t0 * eK;  // dRC/dP
+}
+
 // per-element staging shared by the 16 lanes of an element (all inside one wave)
 struct LhsStage {
     double u[EPB][12];
@@ -178,61 +232,20 @@ __device__ __forceinline__ void lhs_element_block(LhsStage& S, int te, int p, bo
     for (int i = 0; i < 16; ++i) Bk[i] = 0.0;
     if (valid) {
         const int aa = p >> 2, bb = p & 3;
-        const double fact1 = kALPHAM;
-        const double fact2 = kDT * kALPHAF * kGAMMA;
-        const double detJ = s_scal[te][0];
-        double ga[3], gb[3];
+        double ga[3], gb[3], t0[4], t1[4], ca[4], cb[4];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             ga[d] = s_shg[te][aa * 3 + d];
             gb[d] = s_shg[te][bb * 3 + d];
         }
-        const double eK = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
-        // Every term of the reference's per-quadrature-point update (assemble.cu:618-661) is
-        // (quadrature-dependent scalar) x (quadrature-independent geometry product) x detJ*gw
-        // with equal weights, so the 4-point loop reduces to eleven scalar sums followed by ONE
-        // pass over the 16 block entries: ~5x fewer fp64 operations than the literal loop (the
-        // kernel was co-limited by the fp64 pipe).  Same terms, different association: results
-        // differ from the oracle by rounding only (tests bound it at 1e-10).
-        double S_t0 = 0.0, S_t1 = 0.0, S_sa = 0.0, S_sb = 0.0, S_sasb = 0.0, S_t0ca = 0.0, S_t0casb = 0.0, S_sacb = 0.0,
-               S_t0cacb = 0.0, S_t0sb = 0.0, S_t0cb = 0.0;
 #pragma unroll
         for (int iq = 0; iq < 4; ++iq) {
-            const double tau0 = s_tau[te][iq][0], tau1 = s_tau[te][iq][1];
-            const double ca = s_conv[te][aa][iq], cb = s_conv[te][bb][iq];
-            const double sa = shl(aa, iq), sb = shl(bb, iq);
-            const double t0ca = tau0 * ca;
-            S_t0 += tau0;
-            S_t1 += tau1;
-            S_sa += sa;
-            S_sb += sb;
-            S_sasb += sa * sb;
-            S_t0ca += t0ca;
-            S_t0casb += t0ca * sb;
-            S_sacb += sa * cb;
-            S_t0cacb += t0ca * cb;
-            S_t0sb += tau0 * sb;
-            S_t0cb += tau0 * cb;
+            t0[iq] = s_tau[te][iq][0];
+            t1[iq] = s_tau[te][iq][1];
+            ca[iq] = s_conv[te][aa][iq];
+            cb[iq] = s_conv[te][bb][iq];
         }
-        const double w = detJ * GW;
-        const double diag = w * (fact1 * kRHO * S_sasb + fact1 * kRHO * kRHO * S_t0casb + fact2 * kRHO * S_sacb +
-                                 fact2 * kRHO * kRHO * S_t0cacb + 4.0 * fact2 * kMU * eK);
-        const double cK = 4.0 * fact2 * kMU * w, cT = fact2 * kRHO * S_t1 * w;
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj) Bk[ii * 4 + jj] = cK * ga[jj] * gb[ii] + cT * ga[ii] * gb[jj];
-        Bk[0] += diag;
-        Bk[5] += diag;
-        Bk[10] += diag;
-        const double cP0 = w * S_sb, cP1 = w * kRHO * S_t0ca;
-        const double cU0 = w * (fact1 * kRHO * S_t0sb + fact2 * kRHO * S_t0cb), cU1 = w * fact2 * S_sa;
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii) {
-            Bk[ii * 4 + 3] = cP1 * gb[ii] - cP0 * ga[ii];  // dRM/dP
-            Bk[12 + ii] = cU0 * ga[ii] + cU1 * gb[ii];     // dRC/dU
-        }
-        Bk[15] = w * S_t0 * eK;  // dRC/dP
+        lhs_block_eval(aa, bb, ga, gb, s_scal[te][0], t0, t1, ca, cb, Bk);
     }
 }
 
@@ -802,6 +815,186 @@ __global__ __launch_bounds__(256) void gather_ien_kernel(I T_, const I* __restri
     ien_b[i] = ien[(long long)batch_ind[i >> 2] * 4 + (i & 3)];
 }
 
+// ====================================================================================
+//  LHS, row-owner patch form (assembly schedule 3; host/rowpatch.c).  One workgroup owns the
+//  matrix rows of one spatial patch of NODES.  Work item = (tet e, local node a) with node a
+//  owned by the patch: its 4 lanes (lane = b = quadrature point q) evaluate the block row
+//  (a, 0..3) of the tet and add it into an LDS image of the owned CSR rows; afterwards the rows
+//  stream out once (val = beta * val + table; beta = 0 folds the MatrixZero pass into the write).
+//  All staging between the 4 lanes of an item goes through DPP quad broadcasts: no LDS staging,
+//  no barriers inside the item loop.
+// ====================================================================================
+template <int CTRL>
+__device__ __forceinline__ double quad_bcast(double v) {  // CTRL = 0x00 / 0x55 / 0xAA / 0xFF: lane 0..3 of the quad
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(LBLK, 5) void tet_lhs_rowpatch_kernel(I P, const I* __restrict__ p_ioff, const I* __restrict__ p_soff,
+                                                               const I* __restrict__ item_ea,
+                                                               const unsigned short* __restrict__ item_slot,
+                                                               const I* __restrict__ slot_nz, const I* __restrict__ ien,
+                                                               const T* __restrict__ egeo, const T* __restrict__ nodep,
+                                                               T* __restrict__ val, T beta, int dbg) {
+    extern __shared__ double dyn_lds[];
+    double* tab = dyn_lds;  // [16][nsp], entry-major
+    // XCD-aware order: workgroup w runs on XCD w % 8; give every XCD one contiguous range of the spatially
+    // ordered patches so that neighbouring patches (which share halo tets and node records) share an L2
+    const int per = (P + 7) >> 3;
+    const int pid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (pid >= P) return;
+    const int t = threadIdx.x;
+    const int b = t & 3;
+    const int i0 = p_ioff[pid], ni = p_ioff[pid + 1] - i0;
+    const int s0 = p_soff[pid], ns = p_soff[pid + 1] - s0;
+    const int nsp = ns | 1;
+    for (int i = t; i < 16 * nsp; i += LBLK) tab[i] = 0.0;
+    __syncthreads();
+    // the index chain item -> tet -> node of iteration k+1 is fetched while iteration k computes
+    const int nloop = (dbg & 1) ? 0 : ni;
+    int ea_n = 0, slot_n = 0;
+    long long node_n = 0;
+    if ((t >> 2) < nloop) {
+        ea_n = item_ea[i0 + (t >> 2)];
+        slot_n = item_slot[((long long)i0 + (t >> 2)) * 4 + b];
+        node_n = ien[(long long)(ea_n >> 2) * 4 + b];
+    }
+    for (int base = 0; base < nloop; base += LBLK / 4) {
+        const int it = base + (t >> 2);
+        const bool valid = it < ni;  // whole quads are valid or not
+        const int ea = ea_n;
+        const int slot = slot_n;
+        const long long node_b = node_n;
+        const long long e = ea >> 2;
+        const int a = ea & 3;
+        if (it + LBLK / 4 < ni) {
+            ea_n = item_ea[i0 + it + LBLK / 4];
+            slot_n = item_slot[((long long)i0 + it + LBLK / 4) * 4 + b];
+            node_n = ien[(long long)(ea_n >> 2) * 4 + b];
+        }
+        const double* nrec = nodep + node_b * 16 + 3;  // packed node record: u at [3..5]
+        double ub[3] = {nrec[0], nrec[1], nrec[2]};
+        const double* ge = egeo + e * 16;
+        const double2* grec = reinterpret_cast<const double2*>(ge);
+        const double g3 = ge[3];  // rows of J^-1 = shape gradients of nodes 1..3
+        const double2 g45 = grec[2], g67 = grec[3], g89 = grec[4], gab = grec[5], gs = grec[6];
+        const double itr = ge[14];
+        double ga[3], gb[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            ga[d] = ge[a * 3 + d];
+            gb[d] = ge[b * 3 + d];
+        }
+        // u at this lane's quadrature point q = b (qr_wgalpha, :1648-1655): shl(c,q) = SHB + (SHA-SHB)[c == q]
+        double uq[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double sum = ub[d] + dpp_quad<0xB1>(ub[d]);
+            sum += dpp_quad<0x4E>(sum);
+            uq[d] = SHB * sum + (SHA - SHB) * ub[d];
+        }
+        // |J^-1 u|^2 and the stabilisation parameters at q (:587-603); 1/sqrt and sqrt through v_rsq_f64
+        const double c1 = g3 * uq[0] + g45.x * uq[1] + g45.y * uq[2];
+        const double c2 = g67.x * uq[0] + g67.y * uq[1] + g89.x * uq[2];
+        const double c3 = g89.y * uq[0] + gab.x * uq[1] + gab.y * uq[2];
+        const double knu = kMU / kRHO;
+        const double y = c1 * c1 + c2 * c2 + c3 * c3 + (3.0 * knu * knu) * gs.y;
+        const double tau0 = rsqrt(4.0 / (kDT * kDT) + y) * (1.0 / kRHO);
+        const double tau1 = y * rsqrt(y) * itr;
+        const double ca_own = ga[0] * uq[0] + ga[1] * uq[1] + ga[2] * uq[2];
+        // quadrature-point values of the whole quad in every lane
+        double t0[4], t1[4], ca[4], cb[4];
+#define DFL_QUAD_POINT(IQ, CTRL)                                             \
+        {                                                                    \
+            const double q0 = quad_bcast<CTRL>(uq[0]), q1 = quad_bcast<CTRL>(uq[1]), q2 = quad_bcast<CTRL>(uq[2]); \
+            ca[IQ] = ga[0] * q0 + ga[1] * q1 + ga[2] * q2; /* shconv (:574-583) */ \
+            cb[IQ] = gb[0] * q0 + gb[1] * q1 + gb[2] * q2;                   \
+            t0[IQ] = quad_bcast<CTRL>(tau0);                                 \
+            t1[IQ] = quad_bcast<CTRL>(tau1);                                 \
+        }
+        DFL_QUAD_POINT(0, 0x00)
+        DFL_QUAD_POINT(1, 0x55)
+        DFL_QUAD_POINT(2, 0xAA)
+        DFL_QUAD_POINT(3, 0xFF)
+#undef DFL_QUAD_POINT
+        // block (a, b) with b == this lane's quadrature point: the sums over q that carry shl(b, q) collapse to
+        // SHB * (plain sum) + (SHA - SHB) * (own term); same terms as lhs_block_eval, different association
+        double Bk[16];
+        {
+            const double fact1 = kALPHAM;
+            const double fact2 = kDT * kALPHAF * kGAMMA;
+            const double eK = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+            double S_t0 = 0.0, S_t1 = 0.0, S_t0ca = 0.0, S_sacb = 0.0, S_t0cacb = 0.0, S_t0cb = 0.0;
+#pragma unroll
+            for (int iq = 0; iq < 4; ++iq) {
+                const double t0ca = t0[iq] * ca[iq];
+                S_t0 += t0[iq];
+                S_t1 += t1[iq];
+                S_t0ca += t0ca;
+                S_sacb += (iq == a ? SHA : SHB) * cb[iq];
+                S_t0cacb += t0ca * cb[iq];
+                S_t0cb += t0[iq] * cb[iq];
+            }
+            const double S_t0casb = SHB * S_t0ca + (SHA - SHB) * (tau0 * ca_own);
+            const double S_t0sb = SHB * S_t0 + (SHA - SHB) * tau0;
+            const double S_sasb = (a == b) ? (SHA * SHA + 3.0 * SHB * SHB) : (2.0 * SHA * SHB + 2.0 * SHB * SHB);
+            const double S_one = SHA + 3.0 * SHB;  // sum of the shape functions over the quadrature points
+            const double w = gs.x * GW;
+            const double diag = w * (fact1 * kRHO * S_sasb + fact1 * kRHO * kRHO * S_t0casb + fact2 * kRHO * S_sacb +
+                                     fact2 * kRHO * kRHO * S_t0cacb + 4.0 * fact2 * kMU * eK);
+            const double cK = 4.0 * fact2 * kMU * w, cT = fact2 * kRHO * S_t1 * w;
+            double kgb[3], tgb[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                kgb[d] = cK * gb[d];
+                tgb[d] = cT * gb[d];
+            }
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) Bk[ii * 4 + jj] = ga[jj] * kgb[ii] + ga[ii] * tgb[jj];
+            Bk[0] += diag;
+            Bk[5] += diag;
+            Bk[10] += diag;
+            const double cP0 = w * S_one, cP1 = w * kRHO * S_t0ca;
+            const double cU0 = w * (fact1 * kRHO * S_t0sb + fact2 * kRHO * S_t0cb), cU1 = w * fact2 * S_one;
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii) {
+                Bk[ii * 4 + 3] = cP1 * gb[ii] - cP0 * ga[ii];  // dRM/dP
+                Bk[12 + ii] = cU0 * ga[ii] + cU1 * gb[ii];     // dRC/dU
+            }
+            Bk[15] = w * S_t0 * eK;  // dRC/dP
+        }
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) atomicAdd(&tab[i * nsp + slot], Bk[i]);
+        }
+    }
+    __syncthreads();
+    if (dbg & 2) return;
+    // stream the owned rows out: 8 lanes per 128-byte block line
+    const int l8 = t & 7;
+    if (beta == 0.0 || (dbg & 8)) {
+        for (int s = t >> 3; s < ns; s += LBLK / 8) {
+            const long long addr = (long long)slot_nz[s0 + s] * 16 + 2 * l8;
+            double2 nv;
+            nv.x = tab[(2 * l8) * nsp + s];
+            nv.y = tab[(2 * l8 + 1) * nsp + s];
+            *reinterpret_cast<double2*>(val + addr) = nv;
+        }
+    } else {
+        for (int s = t >> 3; s < ns; s += LBLK / 8) {
+            const long long addr = (long long)slot_nz[s0 + s] * 16 + 2 * l8;
+            double2 nv = *reinterpret_cast<const double2*>(val + addr);
+            nv.x = beta * nv.x + tab[(2 * l8) * nsp + s];
+            nv.y = beta * nv.y + tab[(2 * l8 + 1) * nsp + s];
+            *reinterpret_cast<double2*>(val + addr) = nv;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -827,6 +1020,22 @@ void dfl_assemble_tet_lhs_patch(I npatch, I patch_base, const I* p_eoff, const I
     const int NS = (int)max_slots | 1;  // odd stride: conflict-free flush reads
     const size_t shmem = (size_t)16 * NS * sizeof(double);
     tet_lhs_patch_kernel<<<npatch, LBLK, shmem, S(stream)>>>(p_eoff, p_boff, patch_base, ien_p, lslot, blk_nz, egeo_p, nodep, val, NS, g_patch_dbg);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_assemble_tet_lhs_rowpatch(I npatch, const I* p_ioff, const I* p_soff, const I* item_ea, const unsigned short* item_slot,
+                                   const I* slot_nz, const I* ien, const T* egeo, const T* nodep, T* val, T beta,
+                                   I max_slots, void* stream) {
+    if (npatch <= 0) return;
+    const size_t lds = (size_t)16 * (size_t)(max_slots | 1) * sizeof(double);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_rowpatch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    const int grid = 8 * ((npatch + 7) / 8);
+    tet_lhs_rowpatch_kernel<<<grid, LBLK, lds, S(stream)>>>(npatch, p_ioff, p_soff, item_ea, item_slot, slot_nz, ien, egeo,
+                                                            nodep, val, beta, g_patch_dbg);
     DFL_LAUNCH_CHECK();
 }
 

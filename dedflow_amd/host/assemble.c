@@ -16,6 +16,12 @@ void DflSetPatchParameters(index_type leaf, index_type slot_cap) {
     if (leaf > 0) g_patch_leaf = leaf;
     if (slot_cap > 0 && slot_cap <= 511) g_patch_cap = slot_cap;
 }
+/* row-owner patches (schedule 3): nodes per patch and the cap on their summed row lengths (LDS slots) */
+static index_type g_rowpatch_leaf = 16, g_rowpatch_cap = 255;
+void DflSetRowPatchParameters(index_type leaf_nodes, index_type slot_cap) {
+    if (leaf_nodes > 0) g_rowpatch_leaf = leaf_nodes;
+    if (slot_cap > 0 && slot_cap <= 1023) g_rowpatch_cap = slot_cap;
+}
 void DflSetQuiet(b32 quiet) { g_quiet = quiet; }
 b32 DflQuiet(void) { return g_quiet; }
 
@@ -40,6 +46,10 @@ static void ensure_nzmap(Mesh3D* mesh, const CSRAttr* spy) {
 }
 
 void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J) {
+    DflAssembleSystemTetBeta(mesh, wgalpha_dptr, dwgalpha_dptr, F, J, 1.0);
+}
+
+void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J, f64 beta_J) {
     MeshExt* x = (MeshExt*)mesh->ext;
     const Mesh3DData* dev = Mesh3DDevice(mesh);
     const index_type N = Mesh3DNumNode(mesh);
@@ -51,7 +61,7 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
     const CSRAttr* spy = NULL;
     if (J) {
         spy = block_pattern(J, &val);
-        if (DflAssemblyScheduleMode() != 2) ensure_nzmap(mesh, spy);
+        if (DflAssemblyScheduleMode() < 2) ensure_nzmap(mesh, spy);
     }
     /* packed gather records (one line per node) and packed residual accumulator */
     if (!x->nodep) {
@@ -60,7 +70,8 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
     }
     dfl_pack_nodes(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, x->nodep, s);
     const b32 patch_lhs = J && DflAssemblyScheduleMode() == 2;
-    if (J && !patch_lhs && !x->egeo_b) { /* geometry cache in schedule order (static mesh), built once */
+    const b32 rowpatch_lhs = J && DflAssemblyScheduleMode() == 3;
+    if (J && !patch_lhs && !rowpatch_lhs && !x->egeo_b) { /* geometry cache in schedule order (static mesh), built once */
         x->egeo_b = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
         dfl_elem_geometry(mesh->num_tet, x->ien_b, dev->xg, x->egeo_b, s);
     }
@@ -72,7 +83,7 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
         if (bsz == 0) continue;
         const index_type* ien_b = x->ien_b + (size_t)off * 4;
         if (F) DFL_TIMED(DFL_TAG_ASM_RHS, dfl_assemble_tet_rhs(bsz, ien_b, x->nodep, x->Fp, s));
-        if (J && !patch_lhs)
+        if (J && !patch_lhs && !rowpatch_lhs)
             DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, x->egeo_b + (size_t)off * 16,
                                                             x->nodep, val, s));
     }
@@ -93,6 +104,21 @@ void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64*
             DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_patch(np, p0, ps->d_eoff, ps->d_boff, ps->d_ien, ps->d_lslot,
                                                                   ps->d_blk_nz, ps->d_egeo, x->nodep, val, ps->max_slots, s));
         }
+    }
+    if (rowpatch_lhs) { /* schedule 3: ONE launch, every workgroup owns the rows of its node patch (host/rowpatch.c) */
+        if (x->rowpatch && x->rowpatch->attr != spy) {
+            DflFreeRowPatchSchedule(x->rowpatch);
+            x->rowpatch = NULL;
+        }
+        if (!x->rowpatch) {
+            x->rowpatch = DflBuildRowPatchSchedule(mesh, spy, g_rowpatch_leaf, g_rowpatch_cap);
+            x->rowpatch->d_egeo = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
+            dfl_elem_geometry(mesh->num_tet, dev->ien, dev->xg, x->rowpatch->d_egeo, s);
+        }
+        const RowPatchSched* rs = x->rowpatch;
+        DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_rowpatch(rs->num_patch, rs->d_ioff, rs->d_soff, rs->d_item_ea, rs->d_item_slot,
+                                                                 rs->d_slot_nz, dev->ien, rs->d_egeo, x->nodep, val, beta_J,
+                                                                 rs->max_slots, s));
     }
     if (F) dfl_unpack_rhs(N, x->Fp, F, s);
 }
@@ -124,9 +150,11 @@ void AssembleSystem(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J
     index_type num_node = Mesh3DNumNode(mesh);
     hipStream_t s = DflStream();
     if (F) HIPGUARD(hipMemsetAsync(F, 0, (size_t)num_node * sizeof(f64) * BS, s));
-    if (J) MatrixZero(J);
+    /* schedule 3 writes every row of J exactly once: the zero pass folds into that write */
+    const b32 overwrite = J && DflAssemblyScheduleMode() == 3 && Mesh3DNumTet(mesh) && MatrixFSBlockValues(J);
+    if (J && !overwrite) MatrixZero(J);
     if (Mesh3DNumTet(mesh)) {
-        AssembleSystemTet(mesh, wgalpha, dwgalpha, F, J);
+        DflAssembleSystemTetBeta(mesh, wgalpha, dwgalpha, F, J, overwrite ? 0.0 : 1.0);
         AssembleSystemTetFace(mesh, wgalpha, dwgalpha, F, J);
     }
     if (F) HIPGUARD(hipMemsetAsync(F + 4 * (size_t)num_node, 0, (size_t)num_node * sizeof(f64) * 2, s)); /* main.c:63-66 */

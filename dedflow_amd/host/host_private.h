@@ -20,6 +20,20 @@ typedef struct PatchSched {
 PatchSched* DflBuildPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap);
 void DflFreePatchSchedule(PatchSched* ps);
 
+/* Row-owner patch schedule (host/rowpatch.c): spatial patches of nodes, each owning its CSR rows. */
+typedef struct RowPatchSched {
+    const CSRAttr* attr;
+    index_type num_patch, max_slots;
+    index_type* d_ioff;      /* device [num_patch+1] item offsets */
+    index_type* d_soff;      /* device [num_patch+1] slot offsets */
+    index_type* d_item_ea;   /* device [4T] tet*4 + a */
+    uint16_t* d_item_slot;   /* device [4T][4] LDS slot of block (a, b) */
+    index_type* d_slot_nz;   /* device [nnz1] nodal nonzero of each slot */
+    f64* d_egeo;             /* device [T][16] element geometry cache, mesh element order */
+} RowPatchSched;
+RowPatchSched* DflBuildRowPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap);
+void DflFreeRowPatchSchedule(RowPatchSched* ps);
+
 typedef struct MeshExt {
     index_type* ien_b;             /* device [T][4], elements in execution-schedule order */
     index_type sched_num;          /* number of conflict-free launches of the execution schedule */
@@ -34,11 +48,14 @@ typedef struct MeshExt {
     f64* egeo_b;                   /* device [T][16] element geometry cache in schedule order (LHS kernel) */
     f64* nodep;                    /* device [N][16] packed gather records (x,u,phi,T,du,p,dphi,dT) */
     f64* Fp;                       /* device [N][8] packed residual accumulator, zero between calls */
+    RowPatchSched* rowpatch;       /* LHS row-owner patch schedule (mode 3), built on first use */
     PatchSched* patch;             /* LHS patch schedule (assembly schedule mode 2), built on first use */
 } MeshExt;
 
 void DflMeshPrepareFaces(Mesh3D* mesh, index_type group);
 int DflAssemblyScheduleMode(void);
+/* AssembleSystemTet with J = beta_J * J + contributions (beta_J = 0 only takes effect in schedule 3) */
+void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, f64 beta_J);
 b32 DflQuiet(void);
 
 /* profiling tags (runtime.c) */

@@ -92,6 +92,7 @@ void Mesh3DDestroy(Mesh3D* m) {
         CdamFreeDevice(x->ien_b, 0);
         CdamFreeDevice(x->nzmap_b, 0);
         DflFreePatchSchedule(x->patch);
+        DflFreeRowPatchSchedule(x->rowpatch);
         CdamFreeDevice(x->egeo_b, 0);
         CdamFreeDevice(x->nodep, 0);
         CdamFreeDevice(x->Fp, 0);
@@ -137,10 +138,12 @@ void Mesh3DColor(Mesh3D* mesh) {
     mesh->num_color = GetMaxColor(mesh->color, T) + 1;
 }
 
-static int g_sched_mode = 1;
+static int g_sched_mode = 3;
 /* 0: launches follow the reference's JPL color batches one to one (same summation order as
  *    the reference inside every matrix / RHS entry);
- * 1: (default) compact schedule below.  Results differ from mode 0 by summation order only. */
+ * 1: compact schedule below.  Results differ from mode 0 by summation order only;
+ * 2: RHS as 1, Jacobian by tet patches (patch.c);
+ * 3: (default) RHS as 1, Jacobian by row-owner node patches (rowpatch.c). */
 void DflSetAssemblySchedule(int mode) { g_sched_mode = mode; }
 int DflAssemblyScheduleMode(void) { return g_sched_mode; }
 

@@ -389,13 +389,19 @@ index_type DflTimeStep(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* 
 void DflSetQuiet(b32 quiet); /* suppress the reference's stdout chatter ("Assemble: F J", timers) */
 /* which conflict-free launches the assembly kernels execute (set BEFORE Mesh3DGenerateColorBatch):
  *   0  the reference's JPL color batches, one launch per color (reference summation order)
- *   1  (default) compact balanced re-coloring, ~4x fewer / larger launches; mesh->color,
+ *   1  compact balanced re-coloring, ~4x fewer / larger launches; mesh->color,
  *      batch_offset and batch_ind are the reference's JPL result in both modes */
 void DflSetAssemblySchedule(int mode);
 /*   2  as 1 for the RHS; the Jacobian is assembled patch-wise: one workgroup sums all blocks of a spatial
  *      patch of tets in LDS and read-modify-writes each distinct block once per patch (host/patch.c) --
  *      ~3x less HBM traffic than one RMW per tet; LDS atomics => values reproducible to rounding, not bitwise */
 void DflSetPatchParameters(index_type leaf, index_type slot_cap);
+/*   3  (default) as 1 for the RHS; the Jacobian is assembled by row-owner node patches: one launch, every workgroup sums the
+ *      block rows of its nodes in LDS and writes them once (host/rowpatch.c); AssembleSystem skips the zero pass.
+ *      Reproducible to rounding, not bitwise (LDS atomics). */
+/* schedule 3 (row-owner node patches): nodes per patch and cap on their summed nodal row lengths
+ * (one 128-byte LDS line per nodal nonzero; 255 -> 32 KB per workgroup) */
+void DflSetRowPatchParameters(index_type leaf_nodes, index_type slot_cap);
 
 /* ---- arrays / particles (Array.h, Particle.h) ------------------------------------------ */
 typedef struct Array {

@@ -204,6 +204,16 @@ void dfl_assemble_tet_lhs_patch(dfl_index npatch, dfl_index patch_base, const df
                                 const dfl_index* ien_p, const unsigned short* lslot, const dfl_index* blk_nz,
                                 const dfl_value* egeo_p, const dfl_value* nodep, dfl_value* val, dfl_index max_slots,
                                 void* stream);
+/* row-owner patch form (assembly schedule 3, host/rowpatch.c): workgroup p owns the CSR rows of its nodes.
+ * item_ea[i] = tet*4 + a for every (tet, owned node a) pair of the patch, item_slot[i*4 + b] = LDS slot of block
+ * (a, b), slot_nz = nodal nonzero of every slot; `ien` / `egeo` are in the mesh's own element order.
+ * val = beta * val + assembled rows (beta = 0 overwrites: no prior MatrixZero needed). */
+void dfl_assemble_tet_lhs_rowpatch(dfl_index npatch, const dfl_index* p_ioff, const dfl_index* p_soff, const dfl_index* item_ea,
+                                   const unsigned short* item_slot, const dfl_index* slot_nz, const dfl_index* ien,
+                                   const dfl_value* egeo, const dfl_value* nodep, dfl_value* val, dfl_value beta,
+                                   dfl_index max_slots, void* stream);
+/* developer probe of the patch kernel (bit 0 skip element loop, bit 1 skip flush, bit 2 skip LDS adds) */
+void dfl_tune_asm(int flags);
 /* weak-BC faces of one color (src/assemble.cu:1764-1964): face list entries index f2e/forn of the group */
 void dfl_assemble_face(dfl_index n_face, const dfl_index* face_list, const dfl_index* f2e, const dfl_index* forn,
                        const dfl_index* ien, dfl_index N, const dfl_value* xg, const dfl_value* wgalpha,

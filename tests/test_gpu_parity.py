@@ -268,7 +268,7 @@ def test_reference_color_schedule_matches_compact_schedule(api, oracle_lib):
     wg, dwg = synthetic_fields(m)
     F, vals = S.assemble_system(wg, dwg, True, True)
     out = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         P = api.Problem(m, schedule=mode)
         try:
             assert np.array_equal(P.color(), S.color) and np.array_equal(P.batch_ind(), S.batch_ind)
@@ -288,6 +288,42 @@ def test_reference_color_schedule_matches_compact_schedule(api, oracle_lib):
             assert ok, err
     # the two schedules agree to rounding, far inside the parity bar
     assert np.abs(out[0][0] - out[1][0]).max() <= 1e-13 * np.abs(F).max()
+
+
+def test_row_owner_schedule_add_and_overwrite(api):
+    """Schedule 3: AssembleSystemTet keeps the reference's additive contract (assemble twice = 2x), while
+    AssembleSystem (zero + assemble, src/main.c:44-52) overwrites whatever J held before; both across patch sizes."""
+    m = kuhn_cube(7, jitter=0.2)
+    wg, dwg = synthetic_fields(m)
+    L = api.lib()
+    ref = None
+    for leaf, cap in ((16, 255), (3, 40), (64, 1023)):
+        L.DflSetRowPatchParameters(leaf, cap)
+        P = api.Problem(m, schedule=3)
+        try:
+            wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+            L.MatrixZero(P.J)
+            P.assemble_tet(wg_d, dwg_d, None, want_J=True)
+            api.sync()
+            v1 = P.block_values().numpy().copy()
+            P.assemble_tet(wg_d, dwg_d, None, want_J=True)
+            api.sync()
+            v2 = P.block_values().numpy().copy()
+            assert np.abs(v2 - 2.0 * v1).max() <= 1e-13 * np.abs(v1).max()
+            P.assemble_system(wg_d, dwg_d, None, want_J=True)   # J holds 2x: must be overwritten, then faces + BC rows
+            api.sync()
+            v3 = P.block_values().numpy().copy()
+            L.MatrixZero(P.J)
+            P.assemble_system(wg_d, dwg_d, None, want_J=True)
+            api.sync()
+            v4 = P.block_values().numpy()
+            assert np.abs(v3 - v4).max() <= 1e-13 * np.abs(v4).max()
+            if ref is None:
+                ref = v1
+            assert np.abs(v1 - ref).max() <= 1e-13 * np.abs(ref).max()
+        finally:
+            P.close()
+    L.DflSetRowPatchParameters(16, 255)
 
 
 def test_single_tet_all_faces(api, oracle_lib):

@@ -1,4 +1,5 @@
-"""A/B of the Jacobian-assembly schedules (1 = compact colors, 2 = patch/LDS) at M (default 119)."""
+"""A/B of the Jacobian-assembly schedules (1 = compact colors, 2 = tet patches, 3 = row-owner node patches) at M
+(default 119); extra args are mode:leaf:cap triples."""
 import ctypes as C, sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,7 +7,7 @@ from dedflow_amd import api
 from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 119
-configs = [(1, 0, 0)] + [(2, int(a), int(b)) for a, b in (c.split(":") for c in sys.argv[2:])] if len(sys.argv) > 2 else [(1, 0, 0), (2, 96, 448)]
+configs = [(1, 0, 0)] + [(int(m), int(a), int(b)) for m, a, b in (c.split(":") for c in sys.argv[2:])] if len(sys.argv) > 2 else [(1, 0, 0), (2, 64, 320), (3, 16, 255)]
 mesh = kuhn_cube(M, jitter=0.2)
 wg, dwg = synthetic_fields(mesh)
 L = api.lib()
@@ -14,6 +15,8 @@ ref = None
 for mode, leaf, cap in configs:
     if mode == 2:
         L.DflSetPatchParameters(leaf, cap)
+    if mode == 3:
+        L.DflSetRowPatchParameters(leaf, cap)
     t0 = time.perf_counter()
     P = api.Problem(mesh, schedule=mode)
     wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
