@@ -289,7 +289,7 @@ def _declare(L):
     f("dfl_daxpy", None, [i32, f64, vp, vp, vp]); f("dfl_dscal", None, [i32, f64, vp, vp])
     f("dfl_pc_jacobi_setup", None, [i32, vp, vp, vp, vp, vp, vp]); f("dfl_pc_jacobi_apply", None, [i32, i32, vp, vp, vp, vp, vp])
     f("dfl_assemble_tet_lhs", None, [i32, vp, vp, vp, vp, vp, vp])
-    f("dfl_assemble_tet_rhs", None, [i32, vp, vp, vp, vp])
+    f("dfl_assemble_tet_rhs", None, [i32, vp, vp, vp, vp, vp])
     f("dfl_pack_nodes", None, [i32, vp, vp, vp, vp, vp]); f("dfl_unpack_rhs", None, [i32, vp, vp, vp])
     f("ParticleContextCreate", C.POINTER(ParticleContext), [i32]); f("ParticleContextDestroy", None, [C.POINTER(ParticleContext)])
     f("ParticleContextUpdateDevice", None, [C.POINTER(ParticleContext)]); f("ParticleContextUpdateHost", None, [C.POINTER(ParticleContext)])

@@ -382,8 +382,8 @@ __device__ __forceinline__ double dpp_quad(double v) {
 constexpr int NREC = 16;
 constexpr int FREC = 8;  // packed residual record: F_u0 F_u1 F_u2 F_p F_phi F_T pad pad (64 bytes)
 
-__global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict__ ien_b, const T* __restrict__ nodep,
-                                                      T* __restrict__ Fp) {
+__global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict__ ien_b, const T* __restrict__ egeo_b,
+                                                      const T* __restrict__ nodep, T* __restrict__ Fp) {
     __shared__ double s_n[REPB][4][NV + 1];
     const int t = threadIdx.x;
     const int te = t >> 2, a = t & 3;
@@ -405,14 +405,21 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
     if (!valid) return;  // whole 4-lane groups leave together; shuffles below stay inside a group
 
     const int iq = a;
-    double x[12];
+    // cached geometry record (elem_geometry_kernel): the 4 lanes of an element read the same line
+    double shg[12], detJ, gg, itr;
+    {
+        const double2* grec = reinterpret_cast<const double2*>(egeo_b + e * 16);
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) x[b * 3 + d] = s_n[te][b][d];
-    double invJ[9], shg[12], G[9], detJ;
-    tet_geometry(x, invJ, detJ, shg);
-    tet_metric(shg, G);
+        for (int k = 0; k < 6; ++k) {
+            const double2 v = grec[k];
+            shg[2 * k] = v.x;
+            shg[2 * k + 1] = v.y;
+        }
+        const double2 v6 = grec[6], v7 = grec[7];
+        detJ = v6.x;
+        gg = v6.y;
+        itr = v7.x;
+    }
 
     // buffer[comp][b] of LoadElementValueKernel: wg: u0 u1 u2 p phi T ; dwg: du0 du1 du2 p dphi dT
     const int wsrc[6] = {3, 4, 5, 11, 6, 7};
@@ -454,22 +461,24 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
         r += grad[3 * 3 + i];
         rLi[i] = r;
     }
-    // GetStabTau, :444-484
+    // GetStabTau, :444-484.  u.G.u = |J^-1 u|^2 with the rows of J^-1 = shape gradients of nodes 1..3; sum G_ij^2 and
+    // 1/tr G come from the geometry record; 1/sqrt and sqrt through v_rsq_f64 (no fp64 divisions left)
     double tau[4];
     {
-        double t0 = 4.0 / (kDT * kDT), t1 = 0.0, t2 = 0.0;
+        const double t0 = 4.0 / (kDT * kDT);
+        double t1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                t1 += G[i * 3 + j] * uadv[i] * uadv[j];
-                t2 += G[i * 3 + j] * G[i * 3 + j];
-            }
+        for (int r = 0; r < 3; ++r) {
+            const double v = shg[3 + r] * uadv[0] + shg[6 + r] * uadv[1] + shg[9 + r] * uadv[2];
+            t1 += v * v;
+        }
+        const double t2 = gg;
         const double mu = kMU / kRHO, kappa = kKAPPA / (kRHO * kCP);
-        tau[0] = (1.0 / sqrt(t0 + t1 + 3.0 * mu * mu * t2)) / kRHO;
-        tau[1] = sqrt(t1 + 3.0 * mu * mu * t2) / (G[0] + G[4] + G[8]);
-        tau[2] = 1.0 / sqrt(t0 + t1);
-        tau[3] = (1.0 / sqrt(t0 + t1 + 3.0 * kappa * kappa * t2)) / (kRHO * kCP);
+        const double y = t1 + 3.0 * mu * mu * t2;
+        tau[0] = rsqrt(t0 + y) * (1.0 / kRHO);
+        tau[1] = y * rsqrt(y) * itr;
+        tau[2] = rsqrt(t0 + t1);
+        tau[3] = rsqrt(t0 + t1 + 3.0 * kappa * kappa * t2) * (1.0 / (kRHO * kCP));
     }
     double shconv[4];
 #pragma unroll
@@ -1039,9 +1048,9 @@ void dfl_assemble_tet_lhs_rowpatch(I npatch, const I* p_ioff, const I* p_soff, c
     DFL_LAUNCH_CHECK();
 }
 
-void dfl_assemble_tet_rhs(I B, const I* ien_b, const T* nodep, T* Fp, void* stream) {
+void dfl_assemble_tet_rhs(I B, const I* ien_b, const T* egeo_b, const T* nodep, T* Fp, void* stream) {
     if (B <= 0) return;
-    tet_rhs_kernel<<<ceil_div(B, REPB), RBLK, 0, S(stream)>>>(B, ien_b, nodep, Fp);
+    tet_rhs_kernel<<<ceil_div(B, REPB), RBLK, 0, S(stream)>>>(B, ien_b, egeo_b, nodep, Fp);
     DFL_LAUNCH_CHECK();
 }
 

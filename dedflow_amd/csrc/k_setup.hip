@@ -52,32 +52,48 @@ __global__ void priority_mod_kernel(I n, I* color) {
 // ColorElementJPLKernel (color_impl.cu:64-95), synchronous form: local maxima among the
 // still-uncolored vertex neighbours.  Equal priorities are ordered by element id (Q1):
 // identical to the reference whenever the mesh is tie-free.
+// One synchronous JPL round over the work list of still-uncolored elements (`act`, any order):
+// element i is a local maximum when no uncolored neighbour has a larger priority (index breaks ties, Q1).
+// Colored elements hold negative values, so they never win a comparison.
 __global__ void jpl_mark_kernel(const I* __restrict__ ien, const I* __restrict__ rp, const I* __restrict__ ci,
-                                const I* __restrict__ color, I T_, unsigned char* __restrict__ is_max) {
-    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
-    if (i >= T_) return;
+                                const I* __restrict__ color, const I* __restrict__ act, I n_act,
+                                unsigned char* __restrict__ is_max) {
+    const long long idx = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= n_act) return;
+    const long long i = act[idx];
     const I ec = color[i];
-    if (ec < 0) { is_max[i] = 0; return; }
     bool found_max = true;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4 && found_max; ++j) {
         const I node = ien[i * 4 + j];
         for (I k = rp[node]; k < rp[node + 1]; ++k) {
             const I el = ci[k];
             if (el == i) continue;
             const I oc = color[el];
-            if (ec < oc || (ec == oc && i < el)) found_max = false;
+            if (ec < oc || (ec == oc && i < el)) {
+                found_max = false;  // the answer is only this flag: stop at the first larger neighbour
+                break;
+            }
         }
     }
-    is_max[i] = found_max ? 1 : 0;
+    is_max[idx] = found_max ? 1 : 0;
 }
 
-// ReverseColorKernel + SetUpFlagKernel + cub Max (color_impl.cu:120-134,163-177)
-__global__ void jpl_commit_kernel(I* color, const unsigned char* is_max, I c_rev, I T_, int* left) {
-    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
-    if (i >= T_) return;
-    if (is_max[i]) color[i] = c_rev;
-    else if (color[i] >= 0) *left = 1;  // benign same-value race
+// ReverseColorKernel + SetUpFlagKernel + cub Max (color_impl.cu:120-134,163-177): winners take the round's
+// color, the rest are appended (one atomic per wave) to the next round's work list
+__global__ void jpl_commit_kernel(I* __restrict__ color, const unsigned char* __restrict__ is_max, I c_rev,
+                                  const I* __restrict__ act, I n_act, I* __restrict__ next, int* __restrict__ n_next) {
+    const long long idx = (long long)blockIdx.x * BLK + threadIdx.x;
+    const bool in = idx < n_act;
+    const I i = in ? act[idx] : 0;
+    const bool win = in && is_max[idx];
+    if (win) color[i] = c_rev;
+    const bool keep = in && !win;
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & (WAVE - 1);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(n_next, __popcll(m));
+    base = __shfl(base, 0, WAVE);
+    if (keep) next[base + __popcll(m & ((1ULL << lane) - 1ULL))] = i;
 }
 
 __global__ void recover_color_kernel(I* color, I T_) {  // color_impl.cu:136-141
@@ -247,23 +263,30 @@ void GenerateRandomColor(I* color, I n, I max_color) {
 
 void ColorElementJPLTetGPU(const I* ien, const I* rp, const I* ci, I max_color, I* color, I T_) {
     GenerateRandomColor(color, T_, max_color);
+    if (T_ <= 0) return;
     unsigned char* is_max = nullptr;
     int* d_left = nullptr;
+    I* act[2] = {nullptr, nullptr};
     DFL_GUARD(hipMalloc((void**)&is_max, (size_t)T_));
     DFL_GUARD(hipMalloc((void**)&d_left, sizeof(int)));
-    const int grid = ceil_div(T_, BLK);
-    int left = 1;
+    DFL_GUARD(hipMalloc((void**)&act[0], sizeof(I) * (size_t)T_));
+    DFL_GUARD(hipMalloc((void**)&act[1], sizeof(I) * (size_t)T_));
+    iota_kernel<<<ceil_div(T_, BLK), BLK>>>(T_, act[0]);
+    int left = T_;
     I c = 0;
-    for (; c < max_color && left; ++c) {
+    for (; c < max_color && left; ++c) {  // the one host sync per round of the reference (color_impl.cu:176) stays
+        const int grid = ceil_div(left, BLK);
         DFL_GUARD(hipMemsetAsync(d_left, 0, sizeof(int), 0));
-        jpl_mark_kernel<<<grid, BLK>>>(ien, rp, ci, color, T_, is_max);
-        jpl_commit_kernel<<<grid, BLK>>>(color, is_max, -1 - c, T_, d_left);
+        jpl_mark_kernel<<<grid, BLK>>>(ien, rp, ci, color, act[c & 1], left, is_max);
+        jpl_commit_kernel<<<grid, BLK>>>(color, is_max, -1 - c, act[c & 1], left, act[(c + 1) & 1], d_left);
         DFL_GUARD(hipMemcpy(&left, d_left, sizeof(int), hipMemcpyDeviceToHost));
     }
-    recover_color_kernel<<<grid, BLK>>>(color, T_);
+    recover_color_kernel<<<ceil_div(T_, BLK), BLK>>>(color, T_);
     DFL_GUARD(hipDeviceSynchronize());
     DFL_GUARD(hipFree(is_max));
     DFL_GUARD(hipFree(d_left));
+    DFL_GUARD(hipFree(act[0]));
+    DFL_GUARD(hipFree(act[1]));
 }
 
 void GetMaxColorGPU(const I* color, I n, I* h_max) {

@@ -71,7 +71,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
     dfl_pack_nodes(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, x->nodep, s);
     const b32 patch_lhs = J && DflAssemblyScheduleMode() == 2;
     const b32 rowpatch_lhs = J && DflAssemblyScheduleMode() == 3;
-    if (J && !patch_lhs && !rowpatch_lhs && !x->egeo_b) { /* geometry cache in schedule order (static mesh), built once */
+    if (!x->egeo_b) { /* geometry cache in schedule order (static mesh), built once */
         x->egeo_b = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
         dfl_elem_geometry(mesh->num_tet, x->ien_b, dev->xg, x->egeo_b, s);
     }
@@ -82,7 +82,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
         const index_type bsz = x->sched_offset[b + 1] - off;
         if (bsz == 0) continue;
         const index_type* ien_b = x->ien_b + (size_t)off * 4;
-        if (F) DFL_TIMED(DFL_TAG_ASM_RHS, dfl_assemble_tet_rhs(bsz, ien_b, x->nodep, x->Fp, s));
+        if (F) DFL_TIMED(DFL_TAG_ASM_RHS, dfl_assemble_tet_rhs(bsz, ien_b, x->egeo_b + (size_t)off * 16, x->nodep, x->Fp, s));
         if (J && !patch_lhs && !rowpatch_lhs)
             DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, x->egeo_b + (size_t)off * 16,
                                                             x->nodep, val, s));
@@ -112,12 +112,10 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
         }
         if (!x->rowpatch) {
             x->rowpatch = DflBuildRowPatchSchedule(mesh, spy, g_rowpatch_leaf, g_rowpatch_cap);
-            x->rowpatch->d_egeo = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
-            dfl_elem_geometry(mesh->num_tet, dev->ien, dev->xg, x->rowpatch->d_egeo, s);
         }
         const RowPatchSched* rs = x->rowpatch;
         DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_rowpatch(rs->num_patch, rs->d_ioff, rs->d_soff, rs->d_item_ea, rs->d_item_slot,
-                                                                 rs->d_slot_nz, dev->ien, rs->d_egeo, x->nodep, val, beta_J,
+                                                                 rs->d_slot_nz, x->ien_b, x->egeo_b, x->nodep, val, beta_J,
                                                                  rs->max_slots, s));
     }
     if (F) dfl_unpack_rhs(N, x->Fp, F, s);

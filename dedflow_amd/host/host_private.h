@@ -26,10 +26,9 @@ typedef struct RowPatchSched {
     index_type num_patch, max_slots;
     index_type* d_ioff;      /* device [num_patch+1] item offsets */
     index_type* d_soff;      /* device [num_patch+1] slot offsets */
-    index_type* d_item_ea;   /* device [4T] tet*4 + a */
+    index_type* d_item_ea;   /* device [4T] (schedule position of the tet)*4 + a */
     uint16_t* d_item_slot;   /* device [4T][4] LDS slot of block (a, b) */
     index_type* d_slot_nz;   /* device [nnz1] nodal nonzero of each slot */
-    f64* d_egeo;             /* device [T][16] element geometry cache, mesh element order */
 } RowPatchSched;
 RowPatchSched* DflBuildRowPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap);
 void DflFreeRowPatchSchedule(RowPatchSched* ps);
@@ -45,6 +44,7 @@ typedef struct MeshExt {
     index_type* face_color_offset; /* host [face_num_class+1] */
     index_type face_num_class;     /* conflict-free face classes (greedy node coloring of the group's faces) */
     index_type* h_f2e;             /* host copy of bound_f2e */
+    index_type* h_sched_elem;      /* host [T]: element id at each position of the execution schedule */
     f64* egeo_b;                   /* device [T][16] element geometry cache in schedule order (LHS kernel) */
     f64* nodep;                    /* device [N][16] packed gather records (x,u,phi,T,du,p,dphi,dT) */
     f64* Fp;                       /* device [N][8] packed residual accumulator, zero between calls */

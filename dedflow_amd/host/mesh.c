@@ -94,6 +94,7 @@ void Mesh3DDestroy(Mesh3D* m) {
         DflFreePatchSchedule(x->patch);
         DflFreeRowPatchSchedule(x->rowpatch);
         CdamFreeDevice(x->egeo_b, 0);
+        if (x->h_sched_elem) CdamFreeHost(x->h_sched_elem, 0);
         CdamFreeDevice(x->nodep, 0);
         CdamFreeDevice(x->Fp, 0);
         CdamFreeDevice(x->face_list, 0);
@@ -190,7 +191,7 @@ static void build_compact_schedule(Mesh3D* mesh, MeshExt* x) {
     dfl_gather_ien(T, mesh->device->ien, d_ind, x->ien_b, DflStream());
     HIPGUARD(hipStreamSynchronize(DflStream()));
     CdamFreeDevice(d_ind, 0);
-    CdamFreeHost(ind, 0);
+    x->h_sched_elem = ind; /* schedule position -> element id, kept for the row-owner schedule builder */
     CdamFreeHost(cls, 0);
     CdamFreeHost(node_mask, 0);
 }
@@ -210,12 +211,16 @@ void Mesh3DGenerateColorBatch(Mesh3D* mesh) {
     dfl_color_batches(mesh->color, T, nc, mesh->batch_offset, mesh->batch_ind);
     x->ien_b = (index_type*)CdamMallocDevice((ptrdiff_t)T * 4 * SIZE_OF(index_type));
     if (x->sched_offset) CdamFreeHost(x->sched_offset, 0);
+    if (x->h_sched_elem) CdamFreeHost(x->h_sched_elem, 0);
+    x->h_sched_elem = NULL;
     if (DflAssemblyScheduleMode() == 0) {
         /* execution schedule == the reference's JPL color batches */
         x->sched_num = nc;
         x->sched_offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (nc + 1));
         memcpy(x->sched_offset, mesh->batch_offset, sizeof(index_type) * (size_t)(nc + 1));
         dfl_gather_ien(T, mesh->device->ien, mesh->batch_ind, x->ien_b, DflStream());
+        x->h_sched_elem = (index_type*)CdamMallocHost((ptrdiff_t)T * SIZE_OF(index_type));
+        HIPGUARD(hipMemcpy(x->h_sched_elem, mesh->batch_ind, sizeof(index_type) * (size_t)T, D2H));
     } else {
         build_compact_schedule(mesh, x);
     }

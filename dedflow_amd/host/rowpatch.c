@@ -10,6 +10,8 @@
  * HBM, one launch, and `J = contributions` can overwrite (beta = 0) so the separate
  * MatrixZero pass of src/main.c:44 folds into the write.
  * Work is still exactly 16 blocks per tet; only the (tet, a) prologue loads are repeated.
+ * Tets are addressed by their position in the execution schedule, so the kernel shares the
+ * schedule-ordered connectivity and geometry cache (ien_b, egeo_b) with the other kernels.
  */
 #include <string.h>
 #include <omp.h>
@@ -131,12 +133,16 @@ RowPatchSched* DflBuildRowPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_
     index_type* vp = (index_type*)calloc((size_t)N + 1, sizeof(index_type));
     for (size_t i = 0; i < (size_t)T * 4; ++i) vp[ien[i] + 1]++;
     for (index_type n = 0; n < N; ++n) vp[n + 1] += vp[n];
-    index_type* ve = (index_type*)malloc(sizeof(index_type) * (size_t)T * 4); /* tet*4 + a */
+    const index_type* sched_elem = ((MeshExt*)mesh->ext)->h_sched_elem;
+    ASSERT(sched_elem && "Mesh3DGenerateColorBatch must run before the row-owner schedule is built");
+    index_type* ve = (index_type*)malloc(sizeof(index_type) * (size_t)T * 4); /* (schedule position)*4 + a */
     {
         index_type* cur = (index_type*)malloc(sizeof(index_type) * (size_t)N);
         memcpy(cur, vp, sizeof(index_type) * (size_t)N);
-        for (index_type e = 0; e < T; ++e)
-            for (int a = 0; a < 4; ++a) ve[cur[ien[(size_t)e * 4 + a]]++] = e * 4 + a;
+        for (index_type pos = 0; pos < T; ++pos) { /* ve holds schedule positions, ascending inside a node */
+            const index_type e = sched_elem[pos];
+            for (int a = 0; a < 4; ++a) ve[cur[ien[(size_t)e * 4 + a]]++] = pos * 4 + a;
+        }
         free(cur);
     }
 
@@ -189,12 +195,11 @@ RowPatchSched* DflBuildRowPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_
         }
         qsort(it, (size_t)ni, sizeof(Item), cmp_item); /* the items of one tet adjacent: shared prologue lines */
         for (index_type j = 0; j < ni; ++j) {
-            const index_type e = it[j].ea >> 2, a = it[j].ea & 3, n = nodes[it[j].k];
+            const index_type e = sched_elem[it[j].ea >> 2], n = nodes[it[j].k];
             const index_type* nd = ien + (size_t)e * 4;
             item_ea[ioff[p] + j] = it[j].ea;
             for (int b = 0; b < 4; ++b)
                 item_slot[((size_t)ioff[p] + j) * 4 + b] = (uint16_t)(rowbase[it[j].k] + find_nz(rp, ci, n, nd[b]) - rp[n]);
-            UNUSED(a);
         }
         free(rowbase);
         free(it);
@@ -220,6 +225,6 @@ RowPatchSched* DflBuildRowPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_
 void DflFreeRowPatchSchedule(RowPatchSched* ps) {
     if (!ps) return;
     CdamFreeDevice(ps->d_ioff, 0); CdamFreeDevice(ps->d_soff, 0); CdamFreeDevice(ps->d_item_ea, 0);
-    CdamFreeDevice(ps->d_item_slot, 0); CdamFreeDevice(ps->d_slot_nz, 0); CdamFreeDevice(ps->d_egeo, 0);
+    CdamFreeDevice(ps->d_item_slot, 0); CdamFreeDevice(ps->d_slot_nz, 0);
     CdamFreeHost(ps, SIZE_OF(RowPatchSched));
 }

@@ -194,7 +194,8 @@ void dfl_unpack_rhs(dfl_index N, dfl_value* Fp /*[N][8], zeroed on return*/, dfl
 void dfl_elem_geometry(dfl_index T, const dfl_index* ien_x, const dfl_value* xg, dfl_value* egeo, void* stream);
 void dfl_assemble_tet_lhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_index* nzmap_b, const dfl_value* egeo_b,
                           const dfl_value* nodep, dfl_value* val, void* stream);
-void dfl_assemble_tet_rhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_value* nodep, dfl_value* Fp, void* stream);
+void dfl_assemble_tet_rhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_value* egeo_b, const dfl_value* nodep,
+                          dfl_value* Fp, void* stream);
 /* patch form of the LHS assembly (assembly schedule 2): one workgroup per spatial patch of tets sums all
  * (a,b) blocks of the patch in an LDS table (ds_add_f64) and read-modify-writes each distinct block once.
  * Launch = the `npatch` patches [patch_base, patch_base+npatch) of one patch color (no shared nodes).
@@ -206,7 +207,7 @@ void dfl_assemble_tet_lhs_patch(dfl_index npatch, dfl_index patch_base, const df
                                 void* stream);
 /* row-owner patch form (assembly schedule 3, host/rowpatch.c): workgroup p owns the CSR rows of its nodes.
  * item_ea[i] = tet*4 + a for every (tet, owned node a) pair of the patch, item_slot[i*4 + b] = LDS slot of block
- * (a, b), slot_nz = nodal nonzero of every slot; `ien` / `egeo` are in the mesh's own element order.
+ * (a, b), slot_nz = nodal nonzero of every slot; `tet` indexes `ien` / `egeo` (execution-schedule order in the host layer).
  * val = beta * val + assembled rows (beta = 0 overwrites: no prior MatrixZero needed). */
 void dfl_assemble_tet_lhs_rowpatch(dfl_index npatch, const dfl_index* p_ioff, const dfl_index* p_soff, const dfl_index* item_ea,
                                    const unsigned short* item_slot, const dfl_index* slot_nz, const dfl_index* ien,
