@@ -257,6 +257,7 @@ def _declare(L):
     f("DflStream", vp, []); f("DflSetStream", None, [vp]); f("DflSetQuiet", None, [i32])
     f("DflSetAssemblySchedule", None, [C.c_int]); f("DflSetPatchParameters", None, [i32, i32])
     f("DflSetRowPatchParameters", None, [i32, i32]); f("dfl_tune_asm", None, [C.c_int])
+    f("DflSetRhsPatchParameters", None, [i32, i32])
     f("Mesh3DCreate", C.POINTER(Mesh3D), [i32, i32, i32, i32]); f("Mesh3DDestroy", None, [C.POINTER(Mesh3D)])
     f("Mesh3DUpdateDevice", None, [C.POINTER(Mesh3D)]); f("Mesh3DGenerateColorBatch", None, [C.POINTER(Mesh3D)])
     f("Mesh3DSetBound", None, [C.POINTER(Mesh3D), i32, vp, vp, vp, vp, vp])
@@ -289,7 +290,7 @@ def _declare(L):
     f("dfl_daxpy", None, [i32, f64, vp, vp, vp]); f("dfl_dscal", None, [i32, f64, vp, vp])
     f("dfl_pc_jacobi_setup", None, [i32, vp, vp, vp, vp, vp, vp]); f("dfl_pc_jacobi_apply", None, [i32, i32, vp, vp, vp, vp, vp])
     f("dfl_assemble_tet_lhs", None, [i32, vp, vp, vp, vp, vp, vp])
-    f("dfl_assemble_tet_rhs", None, [i32, vp, vp, vp, vp, vp])
+    f("dfl_assemble_tet_rhs", None, [i32, vp, vp, vp, vp])
     f("dfl_pack_nodes", None, [i32, vp, vp, vp, vp, vp]); f("dfl_unpack_rhs", None, [i32, vp, vp, vp])
     f("ParticleContextCreate", C.POINTER(ParticleContext), [i32]); f("ParticleContextDestroy", None, [C.POINTER(ParticleContext)])
     f("ParticleContextUpdateDevice", None, [C.POINTER(ParticleContext)]); f("ParticleContextUpdateHost", None, [C.POINTER(ParticleContext)])

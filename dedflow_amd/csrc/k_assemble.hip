@@ -382,33 +382,15 @@ __device__ __forceinline__ double dpp_quad(double v) {
 constexpr int NREC = 16;
 constexpr int FREC = 8;  // packed residual record: F_u0 F_u1 F_u2 F_p F_phi F_T pad pad (64 bytes)
 
-__global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict__ ien_b, const T* __restrict__ egeo_b,
-                                                      const T* __restrict__ nodep, T* __restrict__ Fp) {
-    __shared__ double s_n[REPB][4][NV + 1];
-    const int t = threadIdx.x;
-    const int te = t >> 2, a = t & 3;
-    const long long e = (long long)blockIdx.x * REPB + te;
-    const bool valid = e < B;
-    long long node = 0;
-    if (valid) {
-        node = ien_b[e * 4 + a];
-        double* s = s_n[te][a];
-        const double2* rec = reinterpret_cast<const double2*>(nodep + node * NREC);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {  // 7 x 16 B out of one line instead of 14 scattered 8-byte gathers
-            const double2 v = rec[k];
-            s[2 * k] = v.x;
-            s[2 * k + 1] = v.y;
-        }
-    }
-    WAVE_SYNC();
-    if (!valid) return;  // whole 4-lane groups leave together; shuffles below stay inside a group
-
+// Residual of one tet on 4 lanes (lane a: node a for the result, quadrature point a for the weak form).
+// r[b] = node record of vertex b (x[3] u[3] phi T du[3] p dphi dT, in LDS); result: mine[0..5] = the 6 residual
+// components of node a summed over the 4 quadrature points (DPP quad reduce-scatter).
+template <bool EGEO>
+__device__ __forceinline__ void rhs_quad(const double* const* r, const double* __restrict__ egeo, int a, double* mine) {
     const int iq = a;
-    // cached geometry record (elem_geometry_kernel): the 4 lanes of an element read the same line
     double shg[12], detJ, gg, itr;
-    {
-        const double2* grec = reinterpret_cast<const double2*>(egeo_b + e * 16);
+    if (EGEO) {  // cached geometry record (elem_geometry_kernel): the 4 lanes of an element read the same line
+        const double2* grec = reinterpret_cast<const double2*>(egeo);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const double2 v = grec[k];
@@ -419,6 +401,18 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
         detJ = v6.x;
         gg = v6.y;
         itr = v7.x;
+    } else {  // from the vertex coordinates in the node records (no extra HBM stream)
+        double x[12], invJ[9], G[9];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) x[b * 3 + d] = r[b][d];
+        tet_geometry(x, invJ, detJ, shg);
+        tet_metric(shg, G);
+        gg = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gg += G[k] * G[k];
+        itr = 1.0 / (G[0] + G[4] + G[8]);
     }
 
     // buffer[comp][b] of LoadElementValueKernel: wg: u0 u1 u2 p phi T ; dwg: du0 du1 du2 p dphi dT
@@ -429,7 +423,7 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
     for (int comp = 0; comp < 6; ++comp) {
         double vb[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) vb[b] = s_n[te][b][wsrc[comp]];
+        for (int b = 0; b < 4; ++b) vb[b] = r[b][wsrc[comp]];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             double s = 0.0;
@@ -441,7 +435,7 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             s += shl(b, iq) * vb[b];
-            sd += shl(b, iq) * s_n[te][b][dsrc[comp]];
+            sd += shl(b, iq) * r[b][dsrc[comp]];
         }
         qw[comp] = s;   // qr_wgalpha[comp][iq]
         qd[comp] = sd;  // qr_dwgalpha[comp][iq]
@@ -519,7 +513,6 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
     // summed over the 4 points: reduce-scatter inside the quad with two DPP exchanges
     // (xor 2 keeps the row pair of the own half, xor 1 keeps the own row).
     (void)wq;
-    double mine[6];
     const bool hi2 = (a >> 1) != 0, hi1 = (a & 1) != 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -555,6 +548,32 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
         const double keep = hi1 ? r1 : r0, send = hi1 ? r0 : r1;
         mine[j] = keep + dpp_quad<0xB1>(send);
     }
+}
+
+__global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict__ ien_b, const T* __restrict__ nodep,
+                                                      T* __restrict__ Fp) {
+    __shared__ double s_n[REPB][4][NV + 1];
+    const int t = threadIdx.x;
+    const int te = t >> 2, a = t & 3;
+    const long long e = (long long)blockIdx.x * REPB + te;
+    const bool valid = e < B;
+    long long node = 0;
+    if (valid) {
+        node = ien_b[e * 4 + a];
+        double* s = s_n[te][a];
+        const double2* rec = reinterpret_cast<const double2*>(nodep + node * NREC);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {  // 7 x 16 B out of one line instead of 14 scattered 8-byte gathers
+            const double2 v = rec[k];
+            s[2 * k] = v.x;
+            s[2 * k + 1] = v.y;
+        }
+    }
+    WAVE_SYNC();
+    if (!valid) return;  // whole 4-lane groups leave together; shuffles below stay inside a group
+    const double* r[4] = {s_n[te][0], s_n[te][1], s_n[te][2], s_n[te][3]};
+    double mine[6];
+    rhs_quad<false>(r, nullptr, a, mine);
     // ElemRHSLocal2Global: non-atomic, race-free inside a class; one 64-byte record per node
     double2* dst = reinterpret_cast<double2*>(Fp + node * FREC);
     double2 f0 = dst[0], f1 = dst[1], f2 = dst[2];
@@ -562,6 +581,86 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
     f1.x += mine[2]; f1.y += mine[3];
     f2.x += mine[4]; f2.y += mine[5];
     dst[0] = f0; dst[1] = f1; dst[2] = f2;
+}
+
+// ---- RHS, patch form (host/patch.c: DflBuildRhsPatchSchedule).  One workgroup = one spatial patch of <= 64 tets:
+// the patch's node records are staged in LDS once (each record is fetched once per patch instead of once per tet),
+// every tet is evaluated by 4 lanes exactly as above, the per-(tet, vertex) results are parked in LDS and summed per
+// patch node in a fixed order (adjacency lists), and ONE partial record per patch node is written.
+constexpr int RP_MAXN = 96;  // node records a patch may stage (the host caps patches at this many distinct nodes)
+constexpr int RP_MAXT = 64;   // tets per patch (the tet loop below takes 64 per trip)
+
+__global__ __launch_bounds__(RBLK) void tet_rhs_patch_kernel(const I* __restrict__ p_eoff, const I* __restrict__ p_noff,
+                                                            const I* __restrict__ pnode, const unsigned char* __restrict__ lien,
+                                                            const unsigned short* __restrict__ adj,
+                                                            const unsigned short* __restrict__ adj_start,
+                                                            const I* __restrict__ epos, const T* __restrict__ egeo_b,
+                                                            const T* __restrict__ nodep, T* __restrict__ partial) {
+    __shared__ double s_rec[RP_MAXN][NV + 1];
+    __shared__ double s_out[RP_MAXT * 4][6 + 1];
+    const int t = threadIdx.x;
+    const int pid = blockIdx.x;
+    const int e0 = p_eoff[pid], ne = p_eoff[pid + 1] - e0;
+    const int n0 = p_noff[pid], nn = p_noff[pid + 1] - n0;
+    const int a = t & 3;
+    // this quad's first tet: local vertex ids and geometry record are requested before the node records are staged
+    uchar4 lnv = make_uchar4(0, 0, 0, 0);
+    double2 grec[8];
+    if ((t >> 2) < ne) {
+        lnv = *reinterpret_cast<const uchar4*>(lien + ((long long)e0 + (t >> 2)) * 4);
+        const double2* gp = reinterpret_cast<const double2*>(egeo_b + (long long)epos[e0 + (t >> 2)] * 16);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) grec[k] = gp[k];
+    }
+    for (int k = t; k < nn * 7; k += RBLK) {
+        const int ln = k / 7, part = k - ln * 7;
+        const double2 v = reinterpret_cast<const double2*>(nodep + (long long)pnode[n0 + ln] * NREC)[part];
+        s_rec[ln][2 * part] = v.x;
+        s_rec[ln][2 * part + 1] = v.y;
+    }
+    __syncthreads();
+    for (int le = t >> 2; le < ne; le += REPB) {  // whole quads
+        if (le >= REPB) {
+            lnv = *reinterpret_cast<const uchar4*>(lien + ((long long)e0 + le) * 4);
+            const double2* gp = reinterpret_cast<const double2*>(egeo_b + (long long)epos[e0 + le] * 16);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) grec[k] = gp[k];
+        }
+        const double* r[4] = {s_rec[lnv.x], s_rec[lnv.y], s_rec[lnv.z], s_rec[lnv.w]};
+        double mine[6];
+        rhs_quad<true>(r, reinterpret_cast<const double*>(grec), a, mine);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s_out[le * 4 + a][j] = mine[j];
+    }
+    __syncthreads();
+    // ordered sum per patch node: contributions in ascending local tet order
+    const unsigned short* st = adj_start + n0 + pid;
+    const unsigned short* ad = adj + (long long)e0 * 4;
+    for (int k = t; k < nn * 6; k += RBLK) {
+        const int ln = k / 6, j = k - ln * 6;
+        double sum = 0.0;
+        for (int q = st[ln]; q < st[ln + 1]; ++q) sum += s_out[ad[q]][j];
+        partial[(long long)n0 * 6 + k] = sum;
+    }
+}
+
+// F (reference layout) += sum of the node's partial records, ascending patch order (fixed => reproducible)
+__global__ __launch_bounds__(256) void rhs_node_sum_kernel(I N, const I* __restrict__ goff, const I* __restrict__ gidx,
+                                                          const T* __restrict__ partial, T* __restrict__ F) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    double f[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (I q = goff[i]; q < goff[i + 1]; ++q) {
+        const double2* src = reinterpret_cast<const double2*>(partial + (long long)gidx[q] * 6);
+        const double2 a0 = src[0], a1 = src[1], a2 = src[2];
+        f[0] += a0.x; f[1] += a0.y; f[2] += a1.x; f[3] += a1.y; f[4] += a2.x; f[5] += a2.y;
+    }
+    F[3 * i + 0] += f[0];
+    F[3 * i + 1] += f[1];
+    F[3 * i + 2] += f[2];
+    F[3LL * N + i] += f[3];
+    F[4LL * N + i] += f[4];
+    F[5LL * N + i] += f[5];
 }
 
 // gather layout: one line per node, written once per assembly call from the reference-layout vectors
@@ -1048,9 +1147,27 @@ void dfl_assemble_tet_lhs_rowpatch(I npatch, const I* p_ioff, const I* p_soff, c
     DFL_LAUNCH_CHECK();
 }
 
-void dfl_assemble_tet_rhs(I B, const I* ien_b, const T* egeo_b, const T* nodep, T* Fp, void* stream) {
+void dfl_assemble_tet_rhs_patch(I npatch, const I* p_eoff, const I* p_noff, const I* pnode, const unsigned char* lien,
+                                 const unsigned short* adj, const unsigned short* adj_start, const I* epos, const T* egeo_b,
+                                 const T* nodep, T* partial, void* stream) {
+    if (npatch <= 0) return;
+    tet_rhs_patch_kernel<<<npatch, RBLK, 0, S(stream)>>>(p_eoff, p_noff, pnode, lien, adj, adj_start, epos, egeo_b, nodep,
+                                                         partial);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_rhs_node_sum(I N, const I* goff, const I* gidx, const T* partial, T* F, void* stream) {
+    if (N <= 0) return;
+    rhs_node_sum_kernel<<<ceil_div(N, 256), 256, 0, S(stream)>>>(N, goff, gidx, partial, F);
+    DFL_LAUNCH_CHECK();
+}
+
+int dfl_rhs_patch_max_nodes(void) { return RP_MAXN; }
+int dfl_rhs_patch_max_tets(void) { return RP_MAXT; }
+
+void dfl_assemble_tet_rhs(I B, const I* ien_b, const T* nodep, T* Fp, void* stream) {
     if (B <= 0) return;
-    tet_rhs_kernel<<<ceil_div(B, REPB), RBLK, 0, S(stream)>>>(B, ien_b, egeo_b, nodep, Fp);
+    tet_rhs_kernel<<<ceil_div(B, REPB), RBLK, 0, S(stream)>>>(B, ien_b, nodep, Fp);
     DFL_LAUNCH_CHECK();
 }
 

@@ -22,6 +22,11 @@ void DflSetRowPatchParameters(index_type leaf_nodes, index_type slot_cap) {
     if (leaf_nodes > 0) g_rowpatch_leaf = leaf_nodes;
     if (slot_cap > 0 && slot_cap <= 1023) g_rowpatch_cap = slot_cap;
 }
+static index_type g_rhspatch_leaf = 64, g_rhspatch_nodes = 64;
+void DflSetRhsPatchParameters(index_type leaf_tets, index_type node_cap) {
+    if (leaf_tets > 0 && leaf_tets <= dfl_rhs_patch_max_tets()) g_rhspatch_leaf = leaf_tets;
+    if (node_cap >= 4 && node_cap <= dfl_rhs_patch_max_nodes()) g_rhspatch_nodes = node_cap;
+}
 void DflSetQuiet(b32 quiet) { g_quiet = quiet; }
 b32 DflQuiet(void) { return g_quiet; }
 
@@ -71,6 +76,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
     dfl_pack_nodes(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, x->nodep, s);
     const b32 patch_lhs = J && DflAssemblyScheduleMode() == 2;
     const b32 rowpatch_lhs = J && DflAssemblyScheduleMode() == 3;
+    const b32 patch_rhs = F && DflAssemblyScheduleMode() >= 2;
     if (!x->egeo_b) { /* geometry cache in schedule order (static mesh), built once */
         x->egeo_b = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
         dfl_elem_geometry(mesh->num_tet, x->ien_b, dev->xg, x->egeo_b, s);
@@ -82,7 +88,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
         const index_type bsz = x->sched_offset[b + 1] - off;
         if (bsz == 0) continue;
         const index_type* ien_b = x->ien_b + (size_t)off * 4;
-        if (F) DFL_TIMED(DFL_TAG_ASM_RHS, dfl_assemble_tet_rhs(bsz, ien_b, x->egeo_b + (size_t)off * 16, x->nodep, x->Fp, s));
+        if (F && !patch_rhs) DFL_TIMED(DFL_TAG_ASM_RHS, dfl_assemble_tet_rhs(bsz, ien_b, x->nodep, x->Fp, s));
         if (J && !patch_lhs && !rowpatch_lhs)
             DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, x->egeo_b + (size_t)off * 16,
                                                             x->nodep, val, s));
@@ -118,7 +124,17 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
                                                                  rs->d_slot_nz, x->ien_b, x->egeo_b, x->nodep, val, beta_J,
                                                                  rs->max_slots, s));
     }
-    if (F) dfl_unpack_rhs(N, x->Fp, F, s);
+    if (patch_rhs) { /* schedules 2, 3: patch-staged residual, two launches, fixed summation order (host/patch.c) */
+        if (!x->rhspatch) x->rhspatch = DflBuildRhsPatchSchedule(mesh, g_rhspatch_leaf, g_rhspatch_nodes);
+        const RhsPatchSched* rp = x->rhspatch;
+        int slot = DflProfileBegin(DFL_TAG_ASM_RHS);
+        dfl_assemble_tet_rhs_patch(rp->num_patch, rp->d_eoff, rp->d_noff, rp->d_pnode, rp->d_lien, rp->d_adj, rp->d_adj_start,
+                                   rp->d_epos, x->egeo_b, x->nodep, rp->d_partial, s);
+        dfl_rhs_node_sum(N, rp->d_goff, rp->d_gidx, rp->d_partial, F, s);
+        DflProfileEnd(slot);
+    } else if (F) {
+        dfl_unpack_rhs(N, x->Fp, F, s);
+    }
 }
 
 void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J) {

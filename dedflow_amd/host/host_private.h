@@ -20,6 +20,24 @@ typedef struct PatchSched {
 PatchSched* DflBuildPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap);
 void DflFreePatchSchedule(PatchSched* ps);
 
+/* RHS patch schedule (host/patch.c): spatial patches of <= 64 tets / <= node_cap nodes; partial residual
+ * records per (patch, node) + a node -> partials list for the ordered second pass. */
+typedef struct RhsPatchSched {
+    index_type num_patch, total_nodes;
+    index_type* d_eoff;      /* device [P+1] tet offsets (patch order) */
+    index_type* d_noff;      /* device [P+1] patch-node offsets = partial record offsets */
+    index_type* d_pnode;     /* device [total_nodes] global node of each patch node */
+    u8* d_lien;              /* device [T][4] local (patch) node index of each tet vertex */
+    uint16_t* d_adj;         /* device [4T] per patch: (local tet)*4 + a grouped by patch node, ascending tet */
+    uint16_t* d_adj_start;   /* device [total_nodes + P] per patch nn+1 group starts */
+    index_type* d_epos;      /* device [T] execution-schedule position of each patch-ordered tet */
+    index_type* d_goff;      /* device [N+1] node -> range of gidx */
+    index_type* d_gidx;      /* device [total_nodes] partial record ids of each node, ascending patch */
+    f64* d_partial;          /* device [total_nodes][6] */
+} RhsPatchSched;
+RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_type node_cap);
+void DflFreeRhsPatchSchedule(RhsPatchSched* ps);
+
 /* Row-owner patch schedule (host/rowpatch.c): spatial patches of nodes, each owning its CSR rows. */
 typedef struct RowPatchSched {
     const CSRAttr* attr;
@@ -48,6 +66,7 @@ typedef struct MeshExt {
     f64* egeo_b;                   /* device [T][16] element geometry cache in schedule order (LHS kernel) */
     f64* nodep;                    /* device [N][16] packed gather records (x,u,phi,T,du,p,dphi,dT) */
     f64* Fp;                       /* device [N][8] packed residual accumulator, zero between calls */
+    RhsPatchSched* rhspatch;       /* RHS patch schedule (modes 2, 3), built on first use */
     RowPatchSched* rowpatch;       /* LHS row-owner patch schedule (mode 3), built on first use */
     PatchSched* patch;             /* LHS patch schedule (assembly schedule mode 2), built on first use */
 } MeshExt;

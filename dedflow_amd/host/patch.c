@@ -24,6 +24,7 @@ typedef struct {
     const index_type* ien; /* host connectivity */
     const index_type *rp, *ci; /* host nodal pattern */
     index_type leaf, cap;
+    int cap_on_nodes;      /* 0: cap bounds the distinct (row,col) blocks of a patch, 1: its distinct nodes */
     Range* out;            /* emitted patches */
     index_type nout, capout;
 } Ctx;
@@ -49,6 +50,20 @@ static index_type patch_blocks(const Ctx* x, index_type lo, index_type hi, index
         const index_type* nd = x->ien + (size_t)x->idx[e] * 4;
         for (int a = 0; a < 4; ++a)
             for (int b = 0; b < 4; ++b) keys[n++] = find_nz(x->rp, x->ci, nd[a], nd[b]);
+    }
+    qsort(keys, (size_t)n, sizeof(index_type), cmp_i32);
+    index_type m = 0;
+    for (index_type i = 0; i < n; ++i)
+        if (i == 0 || keys[i] != keys[i - 1]) keys[m++] = keys[i];
+    return m;
+}
+
+/* distinct nodes of elements idx[lo..hi); sorted unique ids returned in `keys` (room for 4 per element) */
+static index_type patch_nodes(const Ctx* x, index_type lo, index_type hi, index_type* keys) {
+    index_type n = 0;
+    for (index_type e = lo; e < hi; ++e) {
+        const index_type* nd = x->ien + (size_t)x->idx[e] * 4;
+        for (int a = 0; a < 4; ++a) keys[n++] = nd[a];
     }
     qsort(keys, (size_t)n, sizeof(index_type), cmp_i32);
     index_type m = 0;
@@ -91,7 +106,7 @@ static void split(Ctx* x, index_type lo, index_type hi) {
     const index_type n = hi - lo;
     if (n <= x->leaf) {
         index_type* keys = (index_type*)malloc(sizeof(index_type) * (size_t)n * 16);
-        index_type nb = patch_blocks(x, lo, hi, keys);
+        index_type nb = x->cap_on_nodes ? patch_nodes(x, lo, hi, keys) : patch_blocks(x, lo, hi, keys);
         free(keys);
         if (nb <= x->cap || n <= 1) { emit(x, lo, hi); return; }
     }
@@ -105,7 +120,13 @@ static void split(Ctx* x, index_type lo, index_type hi) {
     int ax = 0;
     if (bh[1] - bl[1] > bh[ax] - bl[ax]) ax = 1;
     if (bh[2] - bl[2] > bh[ax] - bl[ax]) ax = 2;
-    const index_type half = n / 2;
+    /* cut at a multiple of the leaf size so that leaves come out full (a 64-tet patch fills a 256-thread
+       workgroup; plain halving leaves them 60 % full on average) */
+    index_type half = n / 2;
+    if (x->cap_on_nodes && n > x->leaf) {
+        const index_type nleaf = (n + x->leaf - 1) / x->leaf;
+        half = (nleaf / 2) * x->leaf;
+    }
     select_kth(x->c, ax, x->idx + lo, n, half);
     if (n > 4096) {
 #pragma omp task
@@ -156,7 +177,7 @@ PatchSched* DflBuildPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type l
     const int verbose = getenv("DFL_PATCH_VERBOSE") != NULL;
     double t0 = omp_get_wtime();
     if (verbose) fprintf(stderr, "[patch] threads=%d T=%d leaf=%d cap=%d\n", nt, T, leaf, slot_cap);
-    Ctx x = {c, idx, ien, rp, ci, leaf, slot_cap, NULL, 0, 1024};
+    Ctx x = {c, idx, ien, rp, ci, leaf, slot_cap, 0, NULL, 0, 1024};
     x.out = (Range*)malloc(sizeof(Range) * (size_t)x.capout);
 #pragma omp parallel num_threads(nt)
 #pragma omp single
@@ -287,4 +308,156 @@ void DflFreePatchSchedule(PatchSched* ps) {
     CdamFreeDevice(ps->d_lslot, 0); CdamFreeDevice(ps->d_blk_nz, 0); CdamFreeDevice(ps->d_egeo, 0);
     if (ps->color_offset) CdamFreeHost(ps->color_offset, 0);
     CdamFreeHost(ps, SIZE_OF(PatchSched));
+}
+
+
+/* ---- RHS patches -------------------------------------------------------------------------
+ * The colored RHS scatter fetches 4 node records and read-modify-writes 4 residual records per
+ * tet, and inside a color no two tets share a node, so none of it is reused on chip (~1 KB/tet of
+ * HBM traffic for 404 B/tet of algorithmic bytes).  Here spatial patches of <= 64 tets stage their
+ * <= node_cap node records in LDS once, sum the residual of every patch node in a FIXED order
+ * (per-patch adjacency lists) and write one partial record per patch node; a second kernel adds,
+ * again in fixed order, the partials of every node into F.  No colors, no atomics, two launches,
+ * bitwise reproducible. */
+RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_type node_cap) {
+    const index_type T = mesh->num_tet, N = mesh->num_node;
+    const index_type* ien = mesh->host->ien;
+    const f64* xg = mesh->host->xg;
+    ASSERT(leaf >= 1 && leaf <= dfl_rhs_patch_max_tets() && node_cap >= 4 && node_cap <= dfl_rhs_patch_max_nodes());
+    RhsPatchSched* ps = (RhsPatchSched*)CdamMallocHost(SIZE_OF(RhsPatchSched));
+    memset(ps, 0, sizeof *ps);
+    f64* c = (f64*)malloc(sizeof(f64) * (size_t)T * 3);
+    index_type* idx = (index_type*)malloc(sizeof(index_type) * (size_t)T);
+#pragma omp parallel for schedule(static) num_threads(8)
+    for (index_type e = 0; e < T; ++e) {
+        for (int d = 0; d < 3; ++d) {
+            f64 s = 0.0;
+            for (int a = 0; a < 4; ++a) s += xg[(size_t)ien[(size_t)e * 4 + a] * 3 + d];
+            c[(size_t)e * 3 + d] = 0.25 * s;
+        }
+        idx[e] = e;
+    }
+    int nt = omp_get_max_threads();
+    if (getenv("DFL_HOST_THREADS")) nt = atoi(getenv("DFL_HOST_THREADS"));
+    if (nt > 16) nt = 16;
+    if (nt < 1) nt = 1;
+    const int verbose = getenv("DFL_PATCH_VERBOSE") != NULL;
+    double t0 = omp_get_wtime();
+    Ctx x = {c, idx, ien, NULL, NULL, leaf, node_cap, 1, NULL, 0, 1024};
+    x.out = (Range*)malloc(sizeof(Range) * (size_t)x.capout);
+#pragma omp parallel num_threads(nt)
+#pragma omp single
+    split(&x, 0, T);
+    qsort(x.out, (size_t)x.nout, sizeof(Range), cmp_range);
+    const index_type P = x.nout;
+
+    /* per patch: node list, local connectivity, adjacency (node -> (tet,a) in ascending tet order) */
+    index_type* eoff = (index_type*)malloc(sizeof(index_type) * ((size_t)P + 1));
+    index_type* noff = (index_type*)malloc(sizeof(index_type) * ((size_t)P + 1));
+    index_type* nn_of = (index_type*)malloc(sizeof(index_type) * (size_t)P);
+    index_type** nodes_of = (index_type**)malloc(sizeof(index_type*) * (size_t)P);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+    for (index_type p = 0; p < P; ++p) {
+        const index_type lo = x.out[p].lo, hi = x.out[p].hi;
+        index_type* keys = (index_type*)malloc(sizeof(index_type) * (size_t)(hi - lo) * 4);
+        nn_of[p] = patch_nodes(&x, lo, hi, keys);
+        nodes_of[p] = keys;
+    }
+    eoff[0] = noff[0] = 0;
+    int64_t totn = 0;
+    for (index_type p = 0; p < P; ++p) {
+        eoff[p + 1] = eoff[p] + (x.out[p].hi - x.out[p].lo);
+        totn += nn_of[p];
+        ASSERT(totn < 2147483647LL);
+        noff[p + 1] = (index_type)totn;
+    }
+    index_type* pnode = (index_type*)malloc(sizeof(index_type) * (size_t)(totn > 0 ? totn : 1));
+    u8* lien = (u8*)malloc((size_t)T * 4);
+    uint16_t* adj = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)T * 4);
+    uint16_t* adj_start = (uint16_t*)malloc(sizeof(uint16_t) * ((size_t)totn + (size_t)P));
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+    for (index_type p = 0; p < P; ++p) {
+        const index_type lo = x.out[p].lo, ne = x.out[p].hi - lo, nn = nn_of[p];
+        const index_type* keys = nodes_of[p];
+        memcpy(pnode + noff[p], keys, sizeof(index_type) * (size_t)nn);
+        uint16_t cnt[256]; /* node_cap <= 255: local node ids are bytes */
+        memset(cnt, 0, sizeof cnt);
+        for (index_type k = 0; k < ne; ++k) {
+            const index_type* nd = ien + (size_t)idx[lo + k] * 4;
+            for (int a = 0; a < 4; ++a) {
+                index_type l = 0, h = nn - 1;
+                while (l < h) {
+                    index_type mid = (l + h) >> 1;
+                    if (keys[mid] < nd[a]) l = mid + 1; else h = mid;
+                }
+                lien[((size_t)eoff[p] + k) * 4 + a] = (u8)l;
+                cnt[l]++;
+            }
+        }
+        uint16_t* st = adj_start + (size_t)noff[p] + p; /* nn + 1 entries */
+        st[0] = 0;
+        for (index_type k = 0; k < nn; ++k) st[k + 1] = (uint16_t)(st[k] + cnt[k]);
+        uint16_t cur[256];
+        memcpy(cur, st, sizeof(uint16_t) * (size_t)nn);
+        for (index_type k = 0; k < ne; ++k)
+            for (int a = 0; a < 4; ++a) {
+                const u8 l = lien[((size_t)eoff[p] + k) * 4 + a];
+                adj[(size_t)eoff[p] * 4 + cur[l]++] = (uint16_t)(k * 4 + a);
+            }
+    }
+    /* position of every patch-ordered tet in the execution schedule (indexes the geometry cache egeo_b) */
+    const index_type* sched_elem = ((MeshExt*)mesh->ext)->h_sched_elem;
+    ASSERT(sched_elem && "Mesh3DGenerateColorBatch must run before the RHS patch schedule is built");
+    index_type* pos_of = (index_type*)malloc(sizeof(index_type) * (size_t)T);
+    for (index_type q = 0; q < T; ++q) pos_of[sched_elem[q]] = q;
+    index_type* ien_p = (index_type*)malloc(sizeof(index_type) * (size_t)T); /* reused name: epos */
+    for (index_type q = 0; q < T; ++q) ien_p[q] = pos_of[idx[q]];
+    free(pos_of);
+    /* node -> its partial records (ascending patch order) */
+    index_type* goff = (index_type*)calloc((size_t)N + 1, sizeof(index_type));
+    for (int64_t i = 0; i < totn; ++i) goff[pnode[i] + 1]++;
+    for (index_type n = 0; n < N; ++n) goff[n + 1] += goff[n];
+    index_type* gidx = (index_type*)malloc(sizeof(index_type) * (size_t)(totn > 0 ? totn : 1));
+    {
+        index_type* cur = (index_type*)malloc(sizeof(index_type) * (size_t)N);
+        memcpy(cur, goff, sizeof(index_type) * (size_t)N);
+        for (int64_t i = 0; i < totn; ++i) gidx[cur[pnode[i]]++] = (index_type)i;
+        free(cur);
+    }
+    ps->num_patch = P;
+    ps->total_nodes = (index_type)totn;
+    ps->d_eoff = (index_type*)CdamMallocDevice(((ptrdiff_t)P + 1) * SIZE_OF(index_type));
+    ps->d_noff = (index_type*)CdamMallocDevice(((ptrdiff_t)P + 1) * SIZE_OF(index_type));
+    ps->d_pnode = (index_type*)CdamMallocDevice((ptrdiff_t)(totn > 0 ? totn : 1) * SIZE_OF(index_type));
+    ps->d_lien = (u8*)CdamMallocDevice((ptrdiff_t)T * 4);
+    ps->d_adj = (uint16_t*)CdamMallocDevice((ptrdiff_t)T * 4 * (ptrdiff_t)sizeof(uint16_t));
+    ps->d_adj_start = (uint16_t*)CdamMallocDevice(((ptrdiff_t)totn + P) * (ptrdiff_t)sizeof(uint16_t));
+    ps->d_epos = (index_type*)CdamMallocDevice((ptrdiff_t)T * SIZE_OF(index_type));
+    ps->d_goff = (index_type*)CdamMallocDevice(((ptrdiff_t)N + 1) * SIZE_OF(index_type));
+    ps->d_gidx = (index_type*)CdamMallocDevice((ptrdiff_t)(totn > 0 ? totn : 1) * SIZE_OF(index_type));
+    ps->d_partial = (f64*)CdamMallocDevice((ptrdiff_t)(totn > 0 ? totn : 1) * 6 * SIZE_OF(f64));
+    HIPGUARD(hipMemcpy(ps->d_eoff, eoff, sizeof(index_type) * ((size_t)P + 1), H2D));
+    HIPGUARD(hipMemcpy(ps->d_noff, noff, sizeof(index_type) * ((size_t)P + 1), H2D));
+    HIPGUARD(hipMemcpy(ps->d_pnode, pnode, sizeof(index_type) * (size_t)totn, H2D));
+    HIPGUARD(hipMemcpy(ps->d_lien, lien, (size_t)T * 4, H2D));
+    HIPGUARD(hipMemcpy(ps->d_adj, adj, sizeof(uint16_t) * (size_t)T * 4, H2D));
+    HIPGUARD(hipMemcpy(ps->d_adj_start, adj_start, sizeof(uint16_t) * ((size_t)totn + (size_t)P), H2D));
+    HIPGUARD(hipMemcpy(ps->d_epos, ien_p, sizeof(index_type) * (size_t)T, H2D));
+    HIPGUARD(hipMemcpy(ps->d_goff, goff, sizeof(index_type) * ((size_t)N + 1), H2D));
+    HIPGUARD(hipMemcpy(ps->d_gidx, gidx, sizeof(index_type) * (size_t)totn, H2D));
+    if (verbose) fprintf(stderr, "[rhspatch] %d patches, %lld patch nodes (%.2f per node) in %.2f s\n", P, (long long)totn,
+                         (double)totn / (double)(N > 0 ? N : 1), omp_get_wtime() - t0);
+    for (index_type p = 0; p < P; ++p) free(nodes_of[p]);
+    free(gidx); free(goff); free(ien_p); free(adj_start); free(adj); free(lien); free(pnode);
+    free(nodes_of); free(nn_of); free(noff); free(eoff); free(x.out); free(idx); free(c);
+    return ps;
+}
+
+void DflFreeRhsPatchSchedule(RhsPatchSched* ps) {
+    if (!ps) return;
+    CdamFreeDevice(ps->d_eoff, 0); CdamFreeDevice(ps->d_noff, 0); CdamFreeDevice(ps->d_pnode, 0);
+    CdamFreeDevice(ps->d_lien, 0); CdamFreeDevice(ps->d_adj, 0); CdamFreeDevice(ps->d_adj_start, 0);
+    CdamFreeDevice(ps->d_epos, 0); CdamFreeDevice(ps->d_goff, 0); CdamFreeDevice(ps->d_gidx, 0);
+    CdamFreeDevice(ps->d_partial, 0);
+    CdamFreeHost(ps, SIZE_OF(RhsPatchSched));
 }

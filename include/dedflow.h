@@ -402,6 +402,8 @@ void DflSetPatchParameters(index_type leaf, index_type slot_cap);
 /* schedule 3 (row-owner node patches): nodes per patch and cap on their summed nodal row lengths
  * (one 128-byte LDS line per nodal nonzero; 255 -> 32 KB per workgroup) */
 void DflSetRowPatchParameters(index_type leaf_nodes, index_type slot_cap);
+/* schedules 2 and 3 assemble the residual by spatial tet patches (<= 64 tets, <= node_cap <= 96 distinct nodes each) */
+void DflSetRhsPatchParameters(index_type leaf_tets, index_type node_cap);
 
 /* ---- arrays / particles (Array.h, Particle.h) ------------------------------------------ */
 typedef struct Array {

@@ -194,8 +194,20 @@ void dfl_unpack_rhs(dfl_index N, dfl_value* Fp /*[N][8], zeroed on return*/, dfl
 void dfl_elem_geometry(dfl_index T, const dfl_index* ien_x, const dfl_value* xg, dfl_value* egeo, void* stream);
 void dfl_assemble_tet_lhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_index* nzmap_b, const dfl_value* egeo_b,
                           const dfl_value* nodep, dfl_value* val, void* stream);
-void dfl_assemble_tet_rhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_value* egeo_b, const dfl_value* nodep,
-                          dfl_value* Fp, void* stream);
+void dfl_assemble_tet_rhs(dfl_index batch_size, const dfl_index* ien_b, const dfl_value* nodep, dfl_value* Fp, void* stream);
+/* patch form of the same residual (host/patch.c: DflBuildRhsPatchSchedule): workgroup p evaluates tets
+ * [p_eoff[p], p_eoff[p+1]) whose vertices are the patch nodes pnode[p_noff[p] + lien[tet*4 + a]], and writes one
+ * 6-component partial record per patch node, partial[(p_noff[p] + k)*6 ..], summed in the order of the adjacency lists
+ * (adj / adj_start).  epos[tet] indexes the geometry cache.  dfl_rhs_node_sum then adds, for every node, its partial
+ * records gidx[goff[n] .. goff[n+1]) in that order into F (reference layout).  No atomics: bitwise reproducible. */
+int dfl_rhs_patch_max_nodes(void);
+int dfl_rhs_patch_max_tets(void);
+void dfl_assemble_tet_rhs_patch(dfl_index npatch, const dfl_index* p_eoff, const dfl_index* p_noff, const dfl_index* pnode,
+                                 const unsigned char* lien, const unsigned short* adj, const unsigned short* adj_start,
+                                 const dfl_index* epos, const dfl_value* egeo_b, const dfl_value* nodep, dfl_value* partial,
+                                 void* stream);
+void dfl_rhs_node_sum(dfl_index N, const dfl_index* goff, const dfl_index* gidx, const dfl_value* partial, dfl_value* F,
+                      void* stream);
 /* patch form of the LHS assembly (assembly schedule 2): one workgroup per spatial patch of tets sums all
  * (a,b) blocks of the patch in an LDS table (ds_add_f64) and read-modify-writes each distinct block once.
  * Launch = the `npatch` patches [patch_base, patch_base+npatch) of one patch color (no shared nodes).

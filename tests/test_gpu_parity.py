@@ -326,6 +326,35 @@ def test_row_owner_schedule_add_and_overwrite(api):
     L.DflSetRowPatchParameters(16, 255)
 
 
+def test_patch_residual_is_reproducible_and_patch_size_independent(api, oracle_lib):
+    """Schedules 2/3 assemble F by spatial tet patches with a fixed summation order: bitwise equal run to run,
+    equal to the oracle within the parity bar for every patch size (incl. 1-tet patches and ragged tails)."""
+    m = kuhn_cube(7, jitter=0.2)
+    S = oracle_lib.System(m)
+    wg, dwg = synthetic_fields(m)
+    F, _ = S.assemble_system(wg, dwg, True, False)
+    L = api.lib()
+    try:
+        for leaf, cap in ((64, 64), (1, 4), (7, 20), (64, 96)):
+            L.DflSetRhsPatchParameters(leaf, cap)
+            P = api.Problem(m, schedule=3)
+            try:
+                wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+                runs = []
+                for rep in range(2):
+                    F_d = api.DeviceArray(6 * S.N)
+                    P.assemble_system(wg_d, dwg_d, F_d, want_J=False)
+                    api.sync()
+                    runs.append(F_d.numpy().copy())
+                assert np.array_equal(runs[0], runs[1])
+                ok, err = close(runs[0], F)
+                assert ok, (leaf, cap, err)
+            finally:
+                P.close()
+    finally:
+        L.DflSetRhsPatchParameters(64, 64)
+
+
 def test_single_tet_all_faces(api, oracle_lib):
     """DBG_TET-like case (src/main.c:357-361): one element, face assembly on a chosen group."""
     m = single_tet()
