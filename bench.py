@@ -112,7 +112,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("DFL_FORCE_DIST") == "1":  # DFL_FORCE_DIST: rehearse the N>1 leg on one rank
         from dedflow_amd import dist_bench
         return dist_bench.run(args, rank, world, local_rank)
 

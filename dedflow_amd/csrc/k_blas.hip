@@ -263,9 +263,32 @@ __global__ void residual_update_kernel(T* beta, T* gv) {
     beta[0] = b0 * gv[0];
 }
 
+// halo pack / unpack: out[i] = x[idx[i]] and x[idx[i]] = in[i]
+__global__ __launch_bounds__(256) void gather_idx_kernel(I n, const I* __restrict__ idx, const T* __restrict__ x,
+                                                        T* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = x[idx[i]];
+}
+__global__ __launch_bounds__(256) void scatter_idx_kernel(I n, const I* __restrict__ idx, const T* __restrict__ in,
+                                                         T* __restrict__ x) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[idx[i]] = in[i];
+}
+
 }  // namespace
 
 extern "C" {
+void dfl_gather_idx(I n, const I* idx, const T* x, T* out, void* stream) {
+    if (n <= 0) return;
+    gather_idx_kernel<<<ceil_div(n, 256), 256, 0, S(stream)>>>(n, idx, x, out);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_scatter_idx(I n, const I* idx, const T* in, T* x, void* stream) {
+    if (n <= 0) return;
+    scatter_idx_kernel<<<ceil_div(n, 256), 256, 0, S(stream)>>>(n, idx, in, x);
+    DFL_LAUNCH_CHECK();
+}
+
 
 int dfl_abi_version(void) { return 1; }
 const char* dfl_last_error(void) { return g_err; }

@@ -23,6 +23,8 @@ arithmetic on the path is in libdedflow.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -273,3 +275,89 @@ class DistSolverComm:
     def install(self, ksp):
         from . import api
         api.lib().KrylovSetComm(ksp, C.byref(self.comm))
+
+
+class RcclSolverComm:
+    """The C-level RCCL communicator (host/comm_rccl.c) behind the same DflComm struct: collectives are enqueued
+    from the C GMRES loop on the library stream, no Python in the iteration.  torch.distributed is only the
+    bootstrap channel for the 128-byte unique id.  `verify()` checks it against the torch.distributed path."""
+
+    def __init__(self, plan: HaloPlan, dist, device):
+        import torch
+        from . import api
+        self.plan, self.dist, self.device, self.torch = plan, dist, device, torch
+        L = self.L = api.lib()
+        vp, i32 = C.c_void_p, C.c_int32
+        L.DflRcclLoad.restype, L.DflRcclLoad.argtypes = C.c_int, [C.c_char_p]
+        L.DflRcclUniqueIdBytes.restype, L.DflRcclUniqueIdBytes.argtypes = C.c_int, []
+        L.DflRcclGetUniqueId.restype, L.DflRcclGetUniqueId.argtypes = C.c_int, [C.c_char_p]
+        L.DflRcclCommCreate.restype, L.DflRcclCommCreate.argtypes = vp, [C.c_char_p, C.c_int, C.c_int]
+        L.DflRcclCommSetHalo.restype, L.DflRcclCommSetHalo.argtypes = None, [vp, i32, i32, vp, vp, vp, vp]
+        L.DflRcclCommVtable.restype, L.DflRcclCommVtable.argtypes = vp, [vp]
+        L.DflRcclCommCounters.restype, L.DflRcclCommCounters.argtypes = None, [vp, vp, vp]
+        L.DflRcclCommDestroy.restype, L.DflRcclCommDestroy.argtypes = None, [vp]
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = bundled if os.path.exists(bundled) else ""     # the RCCL build torch already runs on
+        if L.DflRcclLoad(path.encode()) != 0:
+            raise RuntimeError("RCCL could not be loaded from %r" % path)
+        nbytes = L.DflRcclUniqueIdBytes()
+        buf = C.create_string_buffer(nbytes)
+        if plan.rank == 0 and L.DflRcclGetUniqueId(buf) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=0)
+        torch.cuda.synchronize()
+        self.c = L.DflRcclCommCreate(box[0], plan.rank, plan.world)
+        if not self.c:
+            raise RuntimeError("DflRcclCommCreate failed")
+        sc = np.asarray(plan.send_splits, np.int32)
+        rc = np.asarray(plan.recv_splits, np.int32)
+        si = np.ascontiguousarray(plan.send_all.cpu().numpy().astype(np.int32))
+        ri = np.ascontiguousarray(plan.recv_all.cpu().numpy().astype(np.int32))
+        self._keep = (sc, rc, si, ri)
+        L.DflRcclCommSetHalo(self.c, plan.n_local, plan.n_owned, sc.ctypes.data, si.ctypes.data, rc.ctypes.data, ri.ctypes.data)
+        self.vt = L.DflRcclCommVtable(self.c)
+        self.staged = False
+
+    def _counters(self):
+        a, h = C.c_int64(0), C.c_int64(0)
+        self.L.DflRcclCommCounters(self.c, C.byref(a), C.byref(h))
+        return a.value, h.value
+
+    n_allreduce = property(lambda self: self._counters()[0])
+    n_halo = property(lambda self: self._counters()[1])
+
+    def verify(self):
+        """Halo exchange and all-reduce through the C path against torch.distributed on the same inputs.
+        Returns True on every rank or False on every rank."""
+        from . import api
+        torch, dist, plan = self.torch, self.dist, self.plan
+        vt = api.DflComm.from_address(self.vt)
+        ok = True
+        try:
+            g = torch.Generator(device="cpu").manual_seed(1234 + plan.rank)
+            x = torch.rand(6 * plan.n_local, dtype=torch.float64, generator=g).to(self.device)
+            x1, x2 = x.clone(), x.clone()
+            if plan.world > 1:
+                plan.exchange(x1[:4 * plan.n_local])
+            torch.cuda.synchronize()
+            vt.halo_exchange(vt.ctx, x2.data_ptr())
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.equal(x1, x2))
+            r1 = x[:7].clone()
+            r2 = x[:7].clone()
+            dist.all_reduce(r1)
+            torch.cuda.synchronize()
+            vt.allreduce_sum(vt.ctx, r2.data_ptr(), 7)
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.allclose(r1, r2, rtol=1e-14, atol=0.0))
+        except Exception as exc:  # noqa: BLE001 - any failure means "do not use this path"
+            print("RcclSolverComm.verify: %r" % (exc,), file=sys.stderr)
+            ok = False
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
+
+    def install(self, ksp):
+        from . import api
+        self.L.KrylovSetComm(ksp, C.cast(self.vt, C.POINTER(api.DflComm)))

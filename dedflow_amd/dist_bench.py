@@ -5,6 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -23,7 +24,20 @@ def setup_rank(mesh, rank, world, device, dist, its, staged):
     L.MatrixFSSetOwnedRows.argtypes = [C.c_void_p, C.c_int32]
     L.MatrixFSSetOwnedRows(C.cast(P.J, C.c_void_p), lm.n_owned)
     plan = D.HaloPlan(lm, dist, device, staged)
-    comm = D.DistSolverComm(plan, alloc, dist)
+    comm = None
+    if not staged and os.environ.get("DFL_COMM", "rccl") == "rccl":
+        # C-level RCCL communicator (no Python in the GMRES iteration); checked against torch.distributed on
+        # this very plan before it is trusted, otherwise the torch.distributed callbacks stay in place
+        try:
+            cand = D.RcclSolverComm(plan, dist, device)
+            if cand.verify():
+                comm = cand
+            elif rank == 0:
+                print("dedflow: RCCL communicator failed verification, using torch.distributed callbacks", file=sys.stderr)
+        except Exception as exc:  # noqa: BLE001
+            print("dedflow: RCCL communicator unavailable (%r), using torch.distributed callbacks" % (exc,), file=sys.stderr)
+    if comm is None:
+        comm = D.DistSolverComm(plan, alloc, dist)
     comm.install(P.ksp)
     return lm, alloc, P, plan, comm
 
@@ -130,6 +144,7 @@ def run(args, rank, world, local_rank):
             "per_rank": {"local_tets": [r[0] for r in per_rank], "owned_nodes": [r[1] for r in per_rank],
                          "halo_send_bytes": [r[2] for r in per_rank], "colors": [r[3] for r in per_rank]},
             "redundant_assembly_fraction": sum(r[0] for r in per_rank) / Tg - 1.0,
+            "communicator": type(comm).__name__,
             "collectives_per_step": {"allreduce": comm.n_allreduce // (args.steps + args.warmup),
                                      "halo_exchange": comm.n_halo // (args.steps + args.warmup)},
             "roofline": roofline, "cpu_baseline": None, "setup_s": t_setup,

@@ -1,0 +1,186 @@
+/* RCCL implementation of the DflComm callbacks (include/dedflow.h): the collectives of an
+ * element-partitioned solve are enqueued from C on the library's HIP stream, so a GMRES iteration
+ * involves no host round trip (the torch.distributed callbacks of dedflow_amd/dist.py cross into
+ * Python three times per iteration).
+ *   allreduce_sum : ncclAllReduce in place (CGS coefficients, norms, Newton norms)
+ *   halo_exchange : pack kernel -> one ncclGroup of ncclSend/ncclRecv to/from every neighbour (xGMI
+ *                   is a full mesh: all neighbours at once, no ring) -> unpack kernel
+ * RCCL is bound at run time (dlopen of the path the caller passes, e.g. the librccl.so that
+ * PyTorch-ROCm already loaded), so single-GPU users of libdedflow.so carry no RCCL dependency.
+ * The reference has no multi-GPU path; this file is build-defined. */
+#include <dlfcn.h>
+#include <string.h>
+#include "dedflow.h"
+#include "dedflow_kernels.h"
+#include "host_private.h"
+
+typedef struct { char internal[128]; } rccl_unique_id; /* ncclUniqueId: NCCL_UNIQUE_ID_BYTES = 128 */
+typedef void* rccl_comm;
+enum { RCCL_SUCCESS = 0, RCCL_FLOAT64 = 8, RCCL_SUM = 0 }; /* ncclSuccess, ncclFloat64 (= ncclDouble), ncclSum */
+
+static struct {
+    void* handle;
+    int (*GetUniqueId)(rccl_unique_id*);
+    int (*CommInitRank)(rccl_comm*, int, rccl_unique_id, int);
+    int (*CommDestroy)(rccl_comm);
+    int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm, hipStream_t);
+    int (*Send)(const void*, size_t, int, int, rccl_comm, hipStream_t);
+    int (*Recv)(void*, size_t, int, int, rccl_comm, hipStream_t);
+    int (*GroupStart)(void);
+    int (*GroupEnd)(void);
+    const char* (*GetErrorString)(int);
+} R;
+
+#define RCCLGUARD(call)                                                                             \
+    do {                                                                                            \
+        int rc_ = (call);                                                                           \
+        if (rc_ != RCCL_SUCCESS) {                                                                  \
+            fprintf(stderr, "RCCL error %d (%s) at %s:%d\n", rc_, R.GetErrorString ? R.GetErrorString(rc_) : "?", \
+                    __FILE__, __LINE__);                                                            \
+            ASSERT(FALSE);                                                                          \
+        }                                                                                           \
+    } while (0)
+
+struct DflRcclComm {
+    rccl_comm comm;
+    int rank, world;
+    index_type n_local, n_owned;
+    index_type nsend, nrecv;
+    index_type *send_count, *recv_count; /* host [world], in f64 entries */
+    index_type *d_send_idx, *d_recv_idx; /* device: flat dof indices, concatenated in rank order */
+    f64 *d_send, *d_recv;
+    DflComm vt;
+    int64_t n_allreduce, n_halo;
+};
+
+/* 0 on success; the library stays loaded for the life of the process */
+int DflRcclLoad(const char* path) {
+    if (R.handle) return 0;
+    void* h = dlopen(path && path[0] ? path : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        fprintf(stderr, "DflRcclLoad: %s\n", dlerror());
+        return 1;
+    }
+#define BIND(field, name)                                                   \
+    *(void**)(&R.field) = dlsym(h, name);                                   \
+    if (!R.field) { fprintf(stderr, "DflRcclLoad: %s missing\n", name); return 2; }
+    BIND(GetUniqueId, "ncclGetUniqueId")
+    BIND(CommInitRank, "ncclCommInitRank")
+    BIND(CommDestroy, "ncclCommDestroy")
+    BIND(AllReduce, "ncclAllReduce")
+    BIND(Send, "ncclSend")
+    BIND(Recv, "ncclRecv")
+    BIND(GroupStart, "ncclGroupStart")
+    BIND(GroupEnd, "ncclGroupEnd")
+    BIND(GetErrorString, "ncclGetErrorString")
+#undef BIND
+    R.handle = h;
+    return 0;
+}
+
+int DflRcclUniqueIdBytes(void) { return (int)sizeof(rccl_unique_id); }
+
+/* rank 0 creates the id; the caller broadcasts the bytes to the other ranks by any means */
+int DflRcclGetUniqueId(char* out128) {
+    if (!R.handle) return 1;
+    rccl_unique_id id;
+    memset(&id, 0, sizeof id);
+    int rc = R.GetUniqueId(&id);
+    memcpy(out128, &id, sizeof id);
+    return rc;
+}
+
+static void rccl_allreduce(void* ctx, f64* d_buf, index_type n) {
+    DflRcclComm* c = (DflRcclComm*)ctx;
+    if (n <= 0) return;
+    RCCLGUARD(R.AllReduce(d_buf, d_buf, (size_t)n, RCCL_FLOAT64, RCCL_SUM, c->comm, DflStream()));
+    c->n_allreduce++;
+}
+
+static void rccl_halo(void* ctx, f64* d_x) {
+    DflRcclComm* c = (DflRcclComm*)ctx;
+    hipStream_t s = DflStream();
+    c->n_halo++;
+    if (c->nsend == 0 && c->nrecv == 0) return;
+    dfl_gather_idx(c->nsend, c->d_send_idx, d_x, c->d_send, s);
+    RCCLGUARD(R.GroupStart());
+    index_type so = 0, ro = 0;
+    for (int q = 0; q < c->world; ++q) {
+        if (c->send_count[q]) RCCLGUARD(R.Send(c->d_send + so, (size_t)c->send_count[q], RCCL_FLOAT64, q, c->comm, s));
+        if (c->recv_count[q]) RCCLGUARD(R.Recv(c->d_recv + ro, (size_t)c->recv_count[q], RCCL_FLOAT64, q, c->comm, s));
+        so += c->send_count[q];
+        ro += c->recv_count[q];
+    }
+    RCCLGUARD(R.GroupEnd());
+    dfl_scatter_idx(c->nrecv, c->d_recv_idx, c->d_recv, d_x, s);
+}
+
+/* collective over all ranks: every rank passes the same 128-byte id */
+DflRcclComm* DflRcclCommCreate(const char* id128, int rank, int world) {
+    if (!R.handle) {
+        fprintf(stderr, "DflRcclCommCreate: call DflRcclLoad first\n");
+        return NULL;
+    }
+    DflRcclComm* c = (DflRcclComm*)CdamMallocHost(SIZE_OF(DflRcclComm));
+    memset(c, 0, sizeof *c);
+    rccl_unique_id id;
+    memcpy(&id, id128, sizeof id);
+    c->rank = rank;
+    c->world = world;
+    RCCLGUARD(R.CommInitRank(&c->comm, world, id, rank));
+    c->send_count = (index_type*)CdamMallocHost(SIZE_OF(index_type) * world);
+    c->recv_count = (index_type*)CdamMallocHost(SIZE_OF(index_type) * world);
+    memset(c->send_count, 0, sizeof(index_type) * (size_t)world);
+    memset(c->recv_count, 0, sizeof(index_type) * (size_t)world);
+    c->vt.allreduce_sum = rccl_allreduce;
+    c->vt.halo_exchange = rccl_halo;
+    c->vt.ctx = c;
+    return c;
+}
+
+/* halo plan: send_idx / recv_idx are HOST arrays of flat dof indices into the local [u|p|..] vector,
+ * concatenated in rank order; send_count / recv_count [world] give each rank's share */
+void DflRcclCommSetHalo(DflRcclComm* c, index_type n_local, index_type n_owned, const index_type* send_count,
+                        const index_type* send_idx, const index_type* recv_count, const index_type* recv_idx) {
+    c->n_local = n_local;
+    c->n_owned = n_owned;
+    c->vt.num_owned_node = n_owned;
+    CdamFreeDevice(c->d_send_idx, 0); CdamFreeDevice(c->d_recv_idx, 0);
+    CdamFreeDevice(c->d_send, 0); CdamFreeDevice(c->d_recv, 0);
+    c->d_send_idx = c->d_recv_idx = NULL;
+    c->d_send = c->d_recv = NULL;
+    c->nsend = c->nrecv = 0;
+    for (int q = 0; q < c->world; ++q) {
+        ASSERT(q != c->rank || (send_count[q] == 0 && recv_count[q] == 0));
+        c->send_count[q] = send_count[q];
+        c->recv_count[q] = recv_count[q];
+        c->nsend += send_count[q];
+        c->nrecv += recv_count[q];
+    }
+    if (c->nsend) {
+        c->d_send_idx = (index_type*)CdamMallocDevice((ptrdiff_t)c->nsend * SIZE_OF(index_type));
+        c->d_send = (f64*)CdamMallocDevice((ptrdiff_t)c->nsend * SIZE_OF(f64));
+        HIPGUARD(hipMemcpy(c->d_send_idx, send_idx, sizeof(index_type) * (size_t)c->nsend, H2D));
+    }
+    if (c->nrecv) {
+        c->d_recv_idx = (index_type*)CdamMallocDevice((ptrdiff_t)c->nrecv * SIZE_OF(index_type));
+        c->d_recv = (f64*)CdamMallocDevice((ptrdiff_t)c->nrecv * SIZE_OF(f64));
+        HIPGUARD(hipMemcpy(c->d_recv_idx, recv_idx, sizeof(index_type) * (size_t)c->nrecv, H2D));
+    }
+}
+
+const DflComm* DflRcclCommVtable(const DflRcclComm* c) { return &c->vt; }
+void DflRcclCommCounters(const DflRcclComm* c, int64_t* n_allreduce, int64_t* n_halo) {
+    if (n_allreduce) *n_allreduce = c->n_allreduce;
+    if (n_halo) *n_halo = c->n_halo;
+}
+
+void DflRcclCommDestroy(DflRcclComm* c) {
+    if (!c) return;
+    HIPGUARD(hipStreamSynchronize(DflStream()));
+    if (c->comm) R.CommDestroy(c->comm);
+    CdamFreeDevice(c->d_send_idx, 0); CdamFreeDevice(c->d_recv_idx, 0);
+    CdamFreeDevice(c->d_send, 0); CdamFreeDevice(c->d_recv, 0);
+    CdamFreeHost(c->send_count, 0); CdamFreeHost(c->recv_count, 0);
+    CdamFreeHost(c, SIZE_OF(DflRcclComm));
+}

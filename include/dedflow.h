@@ -370,6 +370,21 @@ typedef struct DflComm {
 void KrylovSetComm(Krylov* krylov, const DflComm* comm);
 const DflComm* KrylovGetComm(const Krylov* krylov); /* NULL on a single GPU */
 
+/* RCCL implementation of DflComm (host/comm_rccl.c): collectives enqueued from C on the library stream.
+ * Bootstrap: every rank DflRcclLoad(path to librccl.so, NULL/"" = "librccl.so.1"); rank 0 DflRcclGetUniqueId and
+ * broadcasts the DflRcclUniqueIdBytes() bytes (MPI, torch.distributed, a file ...); all ranks DflRcclCommCreate
+ * (collective), DflRcclCommSetHalo with their halo plan, KrylovSetComm(ksp, DflRcclCommVtable(c)). */
+typedef struct DflRcclComm DflRcclComm;
+int DflRcclLoad(const char* path);
+int DflRcclUniqueIdBytes(void);
+int DflRcclGetUniqueId(char* out_bytes);
+DflRcclComm* DflRcclCommCreate(const char* id_bytes, int rank, int world);
+void DflRcclCommSetHalo(DflRcclComm* c, index_type n_local, index_type n_owned, const index_type* send_count,
+                        const index_type* send_idx, const index_type* recv_count, const index_type* recv_idx);
+const DflComm* DflRcclCommVtable(const DflRcclComm* c);
+void DflRcclCommCounters(const DflRcclComm* c, int64_t* n_allreduce, int64_t* n_halo);
+void DflRcclCommDestroy(DflRcclComm* c);
+
 /* ---- assembly (assemble.h) ------------------------------------------------------------ */
 void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J);
 void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J);

@@ -48,6 +48,9 @@ void dfl_dset(dfl_index n, dfl_value alpha, dfl_value* x, void* stream);        
 void dfl_pointwise_mult(dfl_index n, const dfl_value* x, const dfl_value* y, dfl_value* z, void* stream); /* VecPointwiseMult */
 void dfl_pointwise_div(dfl_index n, const dfl_value* x, const dfl_value* y, dfl_value* z, void* stream);  /* VecPointwiseDiv  */
 void dfl_pointwise_inv(dfl_index n, dfl_value* x, void* stream);                                          /* VecPointwiseInv  */
+/* halo pack / unpack for element-partitioned runs: out[i] = x[idx[i]];  x[idx[i]] = in[i] (idx unique) */
+void dfl_gather_idx(dfl_index n, const dfl_index* idx, const dfl_value* x, dfl_value* out, void* stream);
+void dfl_scatter_idx(dfl_index n, const dfl_index* idx, const dfl_value* in, dfl_value* x, void* stream);
 /* deterministic two-stage reductions; result written to *d_out (device).  `work`
  * holds at least dfl_reduce_work_size() doubles. */
 dfl_index dfl_reduce_work_size(void);

@@ -165,6 +165,41 @@ def run_gpu(rank, world, M, its):
     P.close()
 
 
+def run_gpu_rccl(rank, world, M, its):
+    """The C-level RCCL communicator on the nccl backend.  A GPU box has one GPU and RCCL refuses two ranks on one
+    device, so this runs with world_size 1: bootstrap (unique id, ncclCommInitRank), in-place ncclAllReduce from the
+    C GMRES loop, empty halo plan, verification against torch.distributed, and the solve equal to the plain
+    single-GPU solve.  The multi-rank send/recv group itself is exercised only by bench.py --gpus N."""
+    import torch
+    import torch.distributed as dist
+    from dedflow_amd import api, dist_bench
+    from dedflow_amd import dist as D
+    from dedflow_amd.meshgen import kuhn_cube
+    assert dist.get_backend() == "nccl"
+    mesh = kuhn_cube(M, jitter=0.2)
+    Sg, wg, dwg, Fg, valsg, xg_, histg, r0g = global_reference(mesh, its)
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    os.environ["DFL_COMM"] = "rccl"
+    lm, alloc, P, plan, comm = dist_bench.setup_rank(mesh, rank, world, device, dist, its, False)
+    assert type(comm).__name__ == "RcclSolverComm", type(comm).__name__
+    Ng, n, no = mesh.num_node, P.N, lm.n_owned
+    wg_t, wg_p = dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(wg, lm, Ng))
+    dwg_t, dwg_p = dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(dwg, lm, Ng))
+    F_t, F_p = dist_bench.device_vector(alloc, torch, device, 6 * n)
+    x_t, x_p = dist_bench.device_vector(alloc, torch, device, 6 * n)
+    Pp = dist_bench._Ptr
+    P.assemble_system(Pp(wg_p), Pp(dwg_p), Pp(F_p), want_J=False)
+    P.assemble_system(Pp(wg_p), Pp(dwg_p), None, want_J=True)
+    it, r0, hist, _ = P.solve(Pp(x_p), Pp(F_p))
+    torch.cuda.synchronize()
+    assert it == its and abs(r0 - r0g) <= 1e-12 * r0g
+    assert np.abs(hist - histg).max() <= 1e-8 * r0g
+    assert comm.n_allreduce >= its and comm.n_halo >= its
+    print("DIST_RCCL_OK", world, comm.n_allreduce, comm.n_halo)
+    P.close()
+
+
 def run_gpu_step(rank, world, M, its):
     """One coupled-free time step (predictor, <=2 Newton iterations with distributed GMRES, corrector) on the
     partitioned mesh against the single-domain oracle driver."""
@@ -218,7 +253,10 @@ if __name__ == "__main__":
     import torch.distributed as dist
     mode, M, its = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    {"cpu": run_cpu, "gpu": run_gpu, "gpu_step": run_gpu_step}[mode](rank, world, M, its)
+    if mode == "gpu_rccl":
+        import torch
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl" if mode == "gpu_rccl" else "gloo", rank=rank, world_size=world)
+    {"cpu": run_cpu, "gpu": run_gpu, "gpu_step": run_gpu_step, "gpu_rccl": run_gpu_rccl}[mode](rank, world, M, its)
     dist.barrier()
     dist.destroy_process_group()

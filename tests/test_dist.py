@@ -50,3 +50,11 @@ def test_distributed_time_step_gpu_gloo(oracle_lib):
     halo exchange of the Newton increment."""
     out = _launch("gpu_step", 2, 6, 0)
     assert "DIST_STEP_OK" in out
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_single_rank_gpu(oracle_lib):
+    """C-level RCCL DflComm (host/comm_rccl.c) on the nccl backend, world_size 1 (one GPU per box; RCCL refuses two
+    ranks on one device): bootstrap, in-stream all-reduce, verification against torch.distributed, solve parity."""
+    out = _launch("gpu_rccl", 1, 8, 30)
+    assert "DIST_RCCL_OK" in out
