@@ -239,6 +239,7 @@ class Particles:
         lib().ParticleContextDestroy(self.ctx)
 
 
+PC_DECOMPOSITION, PC_ILU0 = 0x2, 0x5   # PCType values (include/dedflow.h)
 ALLREDUCE_FN = C.CFUNCTYPE(None, vp, vp, C.c_int32)
 HALO_FN = C.CFUNCTYPE(None, vp, vp)
 
@@ -277,7 +278,9 @@ def _declare(L):
     f("KrylovDestroy", None, [vp]); f("KrylovSolve", None, [vp, C.POINTER(Matrix), vp, vp])
     f("KrylovGetStats", C.POINTER(KrylovStats), [vp]); f("KrylovSetCheckInterval", None, [vp, i32])
     f("KrylovSetVerbose", None, [vp, i32]); f("KrylovSetComm", None, [vp, C.POINTER(DflComm)])
-    f("PCSetup", None, [vp]); f("PCApply", None, [vp, vp, vp])
+    f("PCSetup", None, [vp]); f("PCApply", None, [vp, vp, vp]); f("PCDestroy", None, [vp])
+    f("PCCreateDILU", vp, [C.POINTER(Matrix)]); f("PCDILUGetColors", i32, [vp, vp]); f("PCDILUGetInverseBlocks", vp, [vp])
+    f("KrylovSetPCType", None, [vp, C.c_int]); f("KrylovGetPC", vp, [vp])
     f("AssembleSystemTet", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix)])
     f("AssembleSystemTetFace", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix)])
     f("AssembleSystem", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix), vp, i32])

@@ -1,0 +1,180 @@
+// Multicolor block-DILU preconditioner on the (u,p) block-CSR matrix ("ILU0-style" PC of BASELINE
+// config 5 / SURVEY 8(f)-4; the reference only has the PC_ILU0 enum value, pc.h, no implementation).
+//   M = (E + L) E^-1 (E + U),   E_i = A_ii - sum_{j ~ i, color(j) < color(i)} A_ij E_j^-1 A_ji
+// with L / U the blocks below / above in the node-color order.  Nodes of one color are mutually
+// non-adjacent, so a color is one launch; the two triangular sweeps together read every off-diagonal
+// 128-byte block line once (about the traffic of one SpMV) plus E^-1.
+// Mapping as in the SpMV (k_matrix.hip): 8 lanes per node row, lane l owns block entries (2l, 2l+1).
+#include "dfl_common.hpp"
+
+namespace {
+
+constexpr int BLK = 256;
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ long long xidx(int col, int c, long long N3) { return c < 3 ? 3LL * col + c : N3 + col; }
+
+// C = A * B, 4x4 row-major
+__device__ __forceinline__ void mm4(const double* A, const double* B, double* C) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * B[k * 4 + j];
+            C[i * 4 + j] = s;
+        }
+}
+
+// in-place 4x4 inverse, Gauss-Jordan with partial pivoting; static indexing only (stays in registers)
+__device__ __forceinline__ void inv4(double* a) {
+    double b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = (i % 5 == 0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {  // bring the largest |a[r][c]| of rows c.. up to row c
+            if (fabs(a[r * 4 + c]) > fabs(a[c * 4 + c])) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double t = a[r * 4 + k]; a[r * 4 + k] = a[c * 4 + k]; a[c * 4 + k] = t;
+                    t = b[r * 4 + k]; b[r * 4 + k] = b[c * 4 + k]; b[c * 4 + k] = t;
+                }
+            }
+        }
+        const double ip = 1.0 / a[c * 4 + c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[c * 4 + k] *= ip; b[c * 4 + k] *= ip; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double f = a[r * 4 + c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[r * 4 + k] -= f * a[c * 4 + k]; b[r * 4 + k] -= f * b[c * 4 + k]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = b[i];
+}
+
+__device__ __forceinline__ int find_col(const I* __restrict__ ci, int lo, int hi, int col) {  // ci ascending in [lo, hi)
+    --hi;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ci[mid] < col) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// E^-1 of the rows of one color (all lower colors done): one thread per row
+__global__ __launch_bounds__(BLK) void dilu_setup_kernel(I nrows_c, const I* __restrict__ rows, I nown, const I* __restrict__ rp,
+                                                        const I* __restrict__ ci, const T* __restrict__ val,
+                                                        const unsigned char* __restrict__ color, T* __restrict__ Einv) {
+    const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (t >= nrows_c) return;
+    const int row = rows[t];
+    const int cr = color[row];
+    double E[16];
+    const int s = rp[row], e = rp[row + 1];
+    const int kd = find_col(ci, s, e, row);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) E[i] = val[(long long)kd * 16 + i];
+    for (int k = s; k < e; ++k) {
+        const int j = ci[k];
+        if (j >= nown || color[j] >= cr) continue;
+        const int kk = find_col(ci, rp[j], rp[j + 1], row);  // symmetric pattern: (j, row) exists
+        double Aij[16], Ej[16], Aji[16], P[16], Q[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            Aij[i] = val[(long long)k * 16 + i];
+            Ej[i] = Einv[(long long)j * 16 + i];
+            Aji[i] = val[(long long)kk * 16 + i];
+        }
+        mm4(Aij, Ej, P);
+        mm4(P, Aji, Q);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) E[i] -= Q[i];
+    }
+    inv4(E);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Einv[(long long)row * 16 + i] = E[i];
+}
+
+// one color of a triangular sweep.  FWD: z_i = E_i^-1 (r_i - sum_{color(j)<color(i)} A_ij z_j)
+//                                   BWD: z_i -= E_i^-1 sum_{color(j)>color(i)} A_ij z_j
+template <bool FWD>
+__global__ __launch_bounds__(BLK) void dilu_sweep_kernel(I nrows_c, const I* __restrict__ rows, I N, I nown,
+                                                        const I* __restrict__ rp, const I* __restrict__ ci,
+                                                        const T* __restrict__ val, const unsigned char* __restrict__ color,
+                                                        const T* __restrict__ Einv, const T* __restrict__ r, T* __restrict__ z) {
+    const long long gid = (long long)blockIdx.x * BLK + threadIdx.x;
+    const long long slot = gid >> 3;
+    const int l = threadIdx.x & 7;
+    if (slot >= nrows_c) return;  // whole 8-lane groups leave together
+    const int row = rows[slot];
+    const int cr = color[row];
+    const long long N3 = 3LL * N;
+    const int br = l >> 1;
+    const bool hi = (l & 1);
+    const d2v* __restrict__ v2 = reinterpret_cast<const d2v*>(val) + l;
+    double acc = 0.0;
+    for (int k = rp[row]; k < rp[row + 1]; ++k) {
+        const int c = ci[k];
+        if (c >= nown) continue;  // ghost columns of a partitioned run are left to the Krylov method
+        const int cc = color[c];
+        if (FWD ? (cc < cr) : (cc > cr)) {
+            const d2v a = v2[(long long)k * 8];
+            const long long ia = hi ? 3LL * c + 2 : 3LL * c;
+            const long long ib = hi ? N3 + c : 3LL * c + 1;
+            acc += a.x * z[ia] + a.y * z[ib];
+        }
+    }
+    acc += __shfl_xor(acc, 1, WAVE);  // both lanes of block row `br` hold the row sum
+    const long long yi = xidx(row, br, N3);
+    const double t = FWD ? r[yi] - acc : acc;
+    const int base = (threadIdx.x & (WAVE - 1)) & ~7;
+    const double t0 = __shfl(t, base + (hi ? 4 : 0), WAVE);  // component 2*hi   lives on lanes 4*hi, 4*hi+1
+    const double t1 = __shfl(t, base + (hi ? 6 : 2), WAVE);  // component 2*hi+1 lives on lanes 4*hi+2, ...
+    const d2v ev = reinterpret_cast<const d2v*>(Einv + (long long)row * 16)[l];
+    double part = ev.x * t0 + ev.y * t1;
+    part += __shfl_xor(part, 1, WAVE);
+    if (!hi) {
+        if (FWD) z[yi] = part;
+        else z[yi] -= part;
+    }
+}
+
+__global__ __launch_bounds__(BLK) void copy_tail_kernel(long long begin, long long end, const T* __restrict__ x, T* __restrict__ y) {
+    const long long i = begin + (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i < end) y[i] = x[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+void dfl_dilu_setup_color(I nrows_c, const I* rows, I nown, const I* rp, const I* ci, const T* val, const unsigned char* color,
+                          T* Einv, void* stream) {
+    if (nrows_c <= 0) return;
+    dilu_setup_kernel<<<ceil_div(nrows_c, BLK), BLK, 0, S(stream)>>>(nrows_c, rows, nown, rp, ci, val, color, Einv);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_dilu_sweep_color(int forward, I nrows_c, const I* rows, I N, I nown, const I* rp, const I* ci, const T* val,
+                          const unsigned char* color, const T* Einv, const T* r, T* z, void* stream) {
+    if (nrows_c <= 0) return;
+    const int grid = ceil_div((long long)nrows_c * 8, BLK);
+    if (forward) dilu_sweep_kernel<true><<<grid, BLK, 0, S(stream)>>>(nrows_c, rows, N, nown, rp, ci, val, color, Einv, r, z);
+    else dilu_sweep_kernel<false><<<grid, BLK, 0, S(stream)>>>(nrows_c, rows, N, nown, rp, ci, val, color, Einv, r, z);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_copy_range(int64_t begin, int64_t end, const T* x, T* y, void* stream) {
+    if (end <= begin) return;
+    copy_tail_kernel<<<ceil_div(end - begin, BLK), BLK, 0, S(stream)>>>(begin, end, x, y);
+    DFL_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -88,12 +88,25 @@ __global__ void jpl_commit_kernel(I* __restrict__ color, const unsigned char* __
     const bool win = in && is_max[idx];
     if (win) color[i] = c_rev;
     const bool keep = in && !win;
+    // append the survivors: one atomic per workgroup (a single hot counter serialises ~2 ns per atomic)
+    __shared__ int s_cnt[BLK / WAVE];
+    __shared__ int s_base;
     const unsigned long long m = __ballot(keep);
-    const int lane = threadIdx.x & (WAVE - 1);
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(n_next, __popcll(m));
-    base = __shfl(base, 0, WAVE);
-    if (keep) next[base + __popcll(m & ((1ULL << lane) - 1ULL))] = i;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+    if (lane == 0) s_cnt[wv] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < BLK / WAVE; ++k) {
+            const int c = s_cnt[k];
+            s_cnt[k] = tot;
+            tot += c;
+        }
+        s_base = tot ? atomicAdd(n_next, tot) : 0;
+    }
+    __syncthreads();
+    if (keep) next[s_base + s_cnt[wv] + __popcll(m & ((1ULL << lane) - 1ULL))] = i;
 }
 
 __global__ void recover_color_kernel(I* color, I T_) {  // color_impl.cu:136-141

@@ -200,6 +200,7 @@ typedef struct KrylovExt {
     b32 verbose;
     DflComm comm;
     b32 has_comm;
+    PCType pc_type; /* tree KrylovSolve builds: PC_DECOMPOSITION (reference) or PC_ILU0 */
     /* cached GMRES work space */
     index_type ws_n, ws_maxit;
     f64 *Q, *H, *tmp, *gv, *beta, *res_hist, *nrm, *work;
@@ -226,6 +227,14 @@ static Krylov* krylov_init(index_type max_iter, f64 atol, f64 rtol, void* handle
 const KrylovStats* KrylovGetStats(const Krylov* k) { return &kext(k)->stats; }
 void KrylovSetCheckInterval(Krylov* k, index_type n) { kext(k)->check_interval = n > 0 ? n : 20; }
 void KrylovSetVerbose(Krylov* k, b32 v) { kext(k)->verbose = v; }
+void KrylovSetPCType(Krylov* k, PCType type) {
+    if (kext(k)->pc_type != type) { /* rebuilt at the next KrylovSolve */
+        PCDestroy((PC*)k->pc);
+        k->pc = NULL;
+    }
+    kext(k)->pc_type = type;
+}
+PC* KrylovGetPC(const Krylov* k) { return (PC*)k->pc; }
 const DflComm* KrylovGetComm(const Krylov* k) { return kext(k)->has_comm ? &kext(k)->comm : NULL; }
 void KrylovSetComm(Krylov* k, const DflComm* comm) {
     KrylovExt* x = kext(k);
@@ -280,6 +289,7 @@ static void pc_apply_fused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64*
         return;
     }
     if (d_nrm) dfl_dscal_inv_dev(na, d_nrm, w, DflStream());
+    if (pc && pc->type == PC_ILU0) PCDILUSetActiveLength(pc, na);
     if (pc) PCApply(pc, w, z);
     else dfl_dcopy(na, w, z, DflStream());
 }
@@ -471,7 +481,9 @@ void KrylovSolve(Krylov* ksp, Matrix* A, f64* x, f64* b) {
     PC* pc = (PC*)ksp->pc;
     if (pc == NULL || pc->mat != A) {
         PCDestroy(pc);
-        if (A->type == MAT_TYPE_FS && ((MatrixFS*)A->data)->n_offset >= 4) {
+        if (kext(ksp)->pc_type == PC_ILU0 && MatrixFSBlockValues(A)) {
+            pc = PCCreateDILU(A);
+        } else if (A->type == MAT_TYPE_FS && ((MatrixFS*)A->data)->n_offset >= 4) {
             MatrixFS* fs = (MatrixFS*)A->data;
             index_type n = fs->spy1x1->num_row;
             index_type offset[] = {0 * n, 3 * n, 4 * n, 5 * n};

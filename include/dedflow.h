@@ -329,6 +329,13 @@ PC* PCCreateNone(Matrix* mat, index_type n);
 PC* PCCreateJacobi(Matrix* mat, index_type bs, void* handle);
 PC* PCCreateDecomposition(Matrix* mat, index_type n, const index_type* offset, void* handle);
 PC* PCCreateAMGX(Matrix* mat, void* options); /* returns NULL: NVIDIA-only external library (pc.c:300-304) */
+/* PC_ILU0: multicolor block-DILU on the block-mode (u,p) matrix (host/pc_dilu.c, csrc/k_dilu.hip); build-defined,
+ * the reference only declares the enum value.  KrylovSetPCType(ksp, PC_ILU0) makes KrylovSolve build it instead
+ * of the reference's Jacobi tree (PC_DECOMPOSITION = the reference default). */
+PC* PCCreateDILU(Matrix* mat);
+void PCDILUSetActiveLength(PC* pc, index_type n_active);
+index_type PCDILUGetColors(PC* pc, u8* color_out);
+const f64* PCDILUGetInverseBlocks(PC* pc);
 void PCSetup(PC* pc);
 void PCDestroy(PC* pc);
 void PCApply(PC* pc, f64* x, f64* y);
@@ -360,6 +367,8 @@ const KrylovStats* KrylovGetStats(const Krylov* krylov);
 /* 0: GMRES tests convergence every 20 iterations like the reference (krylov.c:281-290); k>0: every k */
 void KrylovSetCheckInterval(Krylov* krylov, index_type k);
 void KrylovSetVerbose(Krylov* krylov, b32 verbose);
+void KrylovSetPCType(Krylov* krylov, PCType type); /* PC_DECOMPOSITION (default, reference tree) or PC_ILU0 */
+PC* KrylovGetPC(const Krylov* krylov);
 /* optional communicator for element-partitioned runs (one process per GPU); NULL = single GPU */
 typedef struct DflComm {
     void (*allreduce_sum)(void* ctx, f64* d_buf, index_type n); /* in place, device buffer */
