@@ -258,7 +258,7 @@ def _declare(L):
     f("DflStream", vp, []); f("DflSetStream", None, [vp]); f("DflSetQuiet", None, [i32])
     f("DflSetAssemblySchedule", None, [C.c_int]); f("DflSetPatchParameters", None, [i32, i32])
     f("DflSetRowPatchParameters", None, [i32, i32]); f("dfl_tune_asm", None, [C.c_int])
-    f("DflSetRhsPatchParameters", None, [i32, i32])
+    f("DflSetRhsPatchParameters", None, [i32, i32]); f("DflMeshGeometryChanged", None, [C.POINTER(Mesh3D)])
     f("Mesh3DCreate", C.POINTER(Mesh3D), [i32, i32, i32, i32]); f("Mesh3DDestroy", None, [C.POINTER(Mesh3D)])
     f("Mesh3DUpdateDevice", None, [C.POINTER(Mesh3D)]); f("Mesh3DGenerateColorBatch", None, [C.POINTER(Mesh3D)])
     f("Mesh3DSetBound", None, [C.POINTER(Mesh3D), i32, vp, vp, vp, vp, vp])

@@ -28,6 +28,13 @@ void DflSetRhsPatchParameters(index_type leaf_tets, index_type node_cap) {
     if (node_cap >= 4 && node_cap <= dfl_rhs_patch_max_nodes()) g_rhspatch_nodes = node_cap;
 }
 void DflSetQuiet(b32 quiet) { g_quiet = quiet; }
+/* node coordinates were modified (moving mesh): drop the per-element geometry cache, rebuilt at the next assembly */
+void DflMeshGeometryChanged(Mesh3D* mesh) {
+    MeshExt* x = (MeshExt*)mesh->ext;
+    if (!x) return;
+    CdamFreeDevice(x->egeo_b, 0);
+    x->egeo_b = NULL;
+}
 b32 DflQuiet(void) { return g_quiet; }
 
 static const CSRAttr* block_pattern(Matrix* J, value_type** val) {

@@ -139,6 +139,17 @@ static b32 decomposition_is_fused_up(PCDecomposition* d, index_type* N_out) {
 
 static void decomposition_setup(PC* pc) {
     PCDecomposition* d = (PCDecomposition*)pc->data;
+    index_type N;
+    Matrix* A = (Matrix*)pc->mat;
+    if (decomposition_is_fused_up(d, &N) && A && MatrixFSBlockValues(A)) {
+        /* the tree of krylov.c:439-453 on the block-mode matrix: both diagonal extractions and inversions
+           (MatrixGetDiag x2, batched LU, pointwise inverse; pc.c:44-85) in one launch, same arithmetic */
+        const CSRAttr* spy = ((MatrixFS*)A->data)->spy1x1;
+        dfl_pc_jacobi_setup_rows(MatrixFSOwnedRows(A), spy->row_ptr, spy->col_ind, MatrixFSBlockValues(A),
+                                 (value_type*)((PCJacobi*)d->pc[0]->data)->diag, (value_type*)((PCJacobi*)d->pc[1]->data)->diag,
+                                 DflStream());
+        return;
+    }
     for (index_type i = 0; i < d->n_sec; ++i) PCSetup(d->pc[i]);
 }
 static void decomposition_apply(PC* pc, value_type* x, value_type* y) {

@@ -410,6 +410,9 @@ struct ParticleContext;
 index_type DflTimeStep(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* J, f64* F, f64* dx, Krylov* ksp, Dirichlet** bcs,
                        index_type nbc, index_type newton_maxit, struct ParticleContext* pctx, index_type dem_substeps,
                        f64* rnorm_out, f64* rnorm_init_out);
+/* the assembly caches J^-1-derived element geometry per mesh (the reference recomputes it every call); after writing new
+ * node coordinates into Mesh3DDevice(mesh)->xg call this once so the next assembly rebuilds the cache */
+void DflMeshGeometryChanged(Mesh3D* mesh);
 void DflSetQuiet(b32 quiet); /* suppress the reference's stdout chatter ("Assemble: F J", timers) */
 /* which conflict-free launches the assembly kernels execute (set BEFORE Mesh3DGenerateColorBatch):
  *   0  the reference's JPL color batches, one launch per color (reference summation order)

@@ -355,6 +355,38 @@ def test_patch_residual_is_reproducible_and_patch_size_independent(api, oracle_l
         L.DflSetRhsPatchParameters(64, 64)
 
 
+def test_geometry_cache_follows_moved_nodes(api, oracle_lib):
+    """The element-geometry cache is per mesh; after the node coordinates change, DflMeshGeometryChanged makes the next
+    assembly agree with the oracle on the moved mesh (and without it the stale cache is what one gets)."""
+    import copy
+    m = kuhn_cube(5, jitter=0.2)
+    wg, dwg = synthetic_fields(m)
+    P = api.Problem(m)
+    L = api.lib()
+    try:
+        wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+        F_d = api.DeviceArray(6 * P.N)
+        P.assemble_system(wg_d, dwg_d, F_d, want_J=True)
+        m2 = copy.deepcopy(m)
+        m2.xg = np.ascontiguousarray((m.xg.reshape(-1, 3) * np.array([1.0, 1.1, 0.95])).reshape(-1))
+        S2 = oracle_lib.System(m2)
+        F2, vals2 = S2.assemble_system(wg, dwg, True, True)
+        xg_dev = api.DeviceArray(3 * P.N, np.float64, ptr=P.mesh.contents.device.contents.xg, owner=False)
+        xg_dev.upload(m2.xg)
+        L.DflMeshGeometryChanged(P.mesh)
+        F_d.zero()
+        P.assemble_system(wg_d, dwg_d, F_d, want_J=False)
+        P.assemble_system(wg_d, dwg_d, None, want_J=True)
+        api.sync()
+        ok, err = close(F_d.numpy(), F2)
+        assert ok, err
+        for g, o in zip(P.export_values(), vals2):
+            ok, err = close(g, o)
+            assert ok, err
+    finally:
+        P.close()
+
+
 def test_single_tet_all_faces(api, oracle_lib):
     """DBG_TET-like case (src/main.c:357-361): one element, face assembly on a chosen group."""
     m = single_tet()
