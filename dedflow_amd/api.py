@@ -245,7 +245,8 @@ HALO_FN = C.CFUNCTYPE(None, vp, vp)
 
 
 class DflComm(C.Structure):
-    _fields_ = [("allreduce_sum", ALLREDUCE_FN), ("halo_exchange", HALO_FN), ("ctx", vp), ("num_owned_node", C.c_int32)]
+    _fields_ = [("allreduce_sum", ALLREDUCE_FN), ("halo_exchange", HALO_FN), ("ctx", vp), ("num_owned_node", C.c_int32),
+                ("halo_begin", HALO_FN), ("halo_end", HALO_FN), ("num_interior_node", C.c_int32)]
 
 
 def _declare(L):

@@ -27,11 +27,11 @@ __device__ __forceinline__ d2v ld_val(const d2v* p) {
 // U nodal nonzeros per loop trip: all U index loads, then all U value loads, then the 2U
 // gathers are issued before the first FMA -- more bytes in flight per 8-lane row group
 template <bool BETA0, bool NT, int U>
-__global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I nrows, I N, const I* __restrict__ rp, const I* __restrict__ ci,
+__global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I row0, I nrows, I N, const I* __restrict__ rp, const I* __restrict__ ci,
                                                        const T* __restrict__ val, T alpha, const T* __restrict__ x, T beta,
                                                        T* __restrict__ y) {
     const long long gid = (long long)blockIdx.x * BLK + threadIdx.x;
-    const int row = (int)(gid >> 3);
+    const int row = row0 + (int)(gid >> 3);
     const int l = threadIdx.x & 7;
     if (row >= nrows) return;  // whole 8-lane group leaves together
     const long long N3 = 3LL * N;
@@ -287,10 +287,12 @@ __global__ void node_from_row_kernel(I n, I* node, I shape) {
 
 extern "C" {
 
-void dfl_bcsr_spmv_rows(I nrows, I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
-    if (nrows <= 0) return;
-    const int grid = ceil_div((long long)nrows * 8, BLK);
-#define SPMV_LAUNCH(B0, NTV, UV) bcsr_spmv_kernel<B0, NTV, UV><<<grid, BLK, 0, S(stream)>>>(nrows, N, rp, ci, val, alpha, x, beta, y)
+void dfl_bcsr_spmv_range(I row0, I row1, I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y,
+                         void* stream) {
+    if (row1 <= row0) return;
+    const I nrows = row1;
+    const int grid = ceil_div((long long)(row1 - row0) * 8, BLK);
+#define SPMV_LAUNCH(B0, NTV, UV) bcsr_spmv_kernel<B0, NTV, UV><<<grid, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y)
     if (beta == 0.0) {
         switch (g_spmv_variant) {
             case 0: SPMV_LAUNCH(true, false, 2); break;
@@ -303,6 +305,9 @@ void dfl_bcsr_spmv_rows(I nrows, I N, const I* rp, const I* ci, const T* val, T 
     }
 #undef SPMV_LAUNCH
     DFL_LAUNCH_CHECK();
+}
+void dfl_bcsr_spmv_rows(I nrows, I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
+    dfl_bcsr_spmv_range(0, nrows, N, rp, ci, val, alpha, x, beta, y, stream);
 }
 /* kernel-variant selection for A/B measurements (key 0: block-CSR SpMV variant 0..3) */
 void dfl_tune(int key, int value) {

@@ -41,6 +41,7 @@ class LocalMesh:
     ghost_owner: np.ndarray  # owner rank of each ghost node (local ids n_owned..)
     rank: int
     world: int
+    n_interior: int = 0      # local nodes [0, n_interior) are owned AND have no ghost neighbour
 
 
 def partition_rcb(mesh: TetMesh, num_part: int) -> np.ndarray:
@@ -70,8 +71,16 @@ def build_local(mesh: TetMesh, epart: np.ndarray, owner: np.ndarray, rank: int, 
     lien_g = ien[l2g_elem]
     nodes = np.unique(lien_g)
     own_mask = owner[nodes] == rank
-    l2g_node = np.concatenate([nodes[own_mask], nodes[~own_mask]]).astype(np.int64)
+    # owned nodes whose every neighbour is owned come first: their matrix rows read no ghost entry, so the
+    # matvec of those rows can run while the halo exchange is in flight
+    ghost_vertex = owner[lien_g] != rank
+    near_ghost = np.zeros(mesh.num_node, bool)
+    near_ghost[np.unique(lien_g[ghost_vertex.any(axis=1)])] = True
+    interior = own_mask & ~near_ghost[nodes]
+    boundary = own_mask & near_ghost[nodes]
+    l2g_node = np.concatenate([nodes[interior], nodes[boundary], nodes[~own_mask]]).astype(np.int64)
     n_owned = int(own_mask.sum())
+    n_interior = int(interior.sum())
     g2l = np.full(mesh.num_node, -1, np.int64)
     g2l[l2g_node] = np.arange(l2g_node.size)
     e_g2l = np.full(mesh.num_tet, -1, np.int64)
@@ -98,7 +107,7 @@ def build_local(mesh: TetMesh, epart: np.ndarray, owner: np.ndarray, rank: int, 
                  bound_node_offset=np.asarray(node_off, np.int32), bound_node=np.concatenate(bnodes).astype(np.int32),
                  bound_elem_offset=np.asarray(elem_off, np.int32), bound_ien=np.concatenate(bien).astype(np.int32),
                  bound_f2e=np.concatenate(bf2e).astype(np.int32), bound_forn=np.concatenate(bforn).astype(np.int32))
-    return LocalMesh(lm, n_owned, l2g_node, l2g_elem, owner[l2g_node[n_owned:]].astype(np.int32), rank, world)
+    return LocalMesh(lm, n_owned, l2g_node, l2g_elem, owner[l2g_node[n_owned:]].astype(np.int32), rank, world, n_interior)
 
 
 def localize_vector(v: np.ndarray, lm: LocalMesh, N_global: int) -> np.ndarray:
@@ -122,6 +131,7 @@ class HaloPlan:
         self.rank, self.world = lm.rank, lm.world
         n = lm.l2g_node.size
         self.n_local, self.n_owned = n, lm.n_owned
+        self.n_interior = lm.n_interior
         ghosts_g = lm.l2g_node[lm.n_owned:]
         need = {int(q): ghosts_g[lm.ghost_owner == q] for q in np.unique(lm.ghost_owner)}
         gathered = [None] * self.world
@@ -270,7 +280,8 @@ class DistSolverComm:
             self.n_halo += 1
 
         self._a, self._h = api.ALLREDUCE_FN(_allreduce), api.HALO_FN(_halo)
-        self.comm = api.DflComm(self._a, self._h, None, plan.n_owned)
+        # no split exchange on this path (synchronous callbacks); the interior / boundary row split is still used
+        self.comm = api.DflComm(self._a, self._h, None, plan.n_owned, api.HALO_FN(), api.HALO_FN(), plan.n_interior)
 
     def install(self, ksp):
         from . import api
@@ -316,6 +327,8 @@ class RcclSolverComm:
         ri = np.ascontiguousarray(plan.recv_all.cpu().numpy().astype(np.int32))
         self._keep = (sc, rc, si, ri)
         L.DflRcclCommSetHalo(self.c, plan.n_local, plan.n_owned, sc.ctypes.data, si.ctypes.data, rc.ctypes.data, ri.ctypes.data)
+        L.DflRcclCommSetInterior.restype, L.DflRcclCommSetInterior.argtypes = None, [vp, i32]
+        L.DflRcclCommSetInterior(self.c, plan.n_interior)
         self.vt = L.DflRcclCommVtable(self.c)
         self.staged = False
 
@@ -344,6 +357,12 @@ class RcclSolverComm:
             vt.halo_exchange(vt.ctx, x2.data_ptr())
             torch.cuda.synchronize()
             ok = ok and bool(torch.equal(x1, x2))
+            x3 = x.clone()
+            torch.cuda.synchronize()
+            vt.halo_begin(vt.ctx, x3.data_ptr())      # split form: side stream + events
+            vt.halo_end(vt.ctx, x3.data_ptr())
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.equal(x1, x3))
             r1 = x[:7].clone()
             r2 = x[:7].clone()
             dist.all_reduce(r1)

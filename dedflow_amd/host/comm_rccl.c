@@ -51,6 +51,8 @@ struct DflRcclComm {
     f64 *d_send, *d_recv;
     DflComm vt;
     int64_t n_allreduce, n_halo;
+    hipStream_t side;            /* non-blocking stream the split halo exchange runs on */
+    hipEvent_t ev_ready, ev_done;
 };
 
 /* 0 on success; the library stays loaded for the life of the process */
@@ -97,10 +99,7 @@ static void rccl_allreduce(void* ctx, f64* d_buf, index_type n) {
     c->n_allreduce++;
 }
 
-static void rccl_halo(void* ctx, f64* d_x) {
-    DflRcclComm* c = (DflRcclComm*)ctx;
-    hipStream_t s = DflStream();
-    c->n_halo++;
+static void rccl_halo_on(DflRcclComm* c, f64* d_x, hipStream_t s) {
     if (c->nsend == 0 && c->nrecv == 0) return;
     dfl_gather_idx(c->nsend, c->d_send_idx, d_x, c->d_send, s);
     RCCLGUARD(R.GroupStart());
@@ -113,6 +112,28 @@ static void rccl_halo(void* ctx, f64* d_x) {
     }
     RCCLGUARD(R.GroupEnd());
     dfl_scatter_idx(c->nrecv, c->d_recv_idx, c->d_recv, d_x, s);
+}
+
+static void rccl_halo(void* ctx, f64* d_x) {
+    DflRcclComm* c = (DflRcclComm*)ctx;
+    c->n_halo++;
+    rccl_halo_on(c, d_x, DflStream());
+}
+
+/* split form: the exchange runs on a side stream behind an event recorded on the library stream (d_x is complete),
+ * the library stream goes on with the interior rows and waits for the side stream in halo_end */
+static void rccl_halo_begin(void* ctx, f64* d_x) {
+    DflRcclComm* c = (DflRcclComm*)ctx;
+    c->n_halo++;
+    HIPGUARD(hipEventRecord(c->ev_ready, DflStream()));
+    HIPGUARD(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+    rccl_halo_on(c, d_x, c->side);
+    HIPGUARD(hipEventRecord(c->ev_done, c->side));
+}
+static void rccl_halo_end(void* ctx, f64* d_x) {
+    DflRcclComm* c = (DflRcclComm*)ctx;
+    UNUSED(d_x);
+    HIPGUARD(hipStreamWaitEvent(DflStream(), c->ev_done, 0));
 }
 
 /* collective over all ranks: every rank passes the same 128-byte id */
@@ -132,8 +153,13 @@ DflRcclComm* DflRcclCommCreate(const char* id128, int rank, int world) {
     c->recv_count = (index_type*)CdamMallocHost(SIZE_OF(index_type) * world);
     memset(c->send_count, 0, sizeof(index_type) * (size_t)world);
     memset(c->recv_count, 0, sizeof(index_type) * (size_t)world);
+    HIPGUARD(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIPGUARD(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    HIPGUARD(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     c->vt.allreduce_sum = rccl_allreduce;
     c->vt.halo_exchange = rccl_halo;
+    c->vt.halo_begin = rccl_halo_begin;
+    c->vt.halo_end = rccl_halo_end;
     c->vt.ctx = c;
     return c;
 }
@@ -169,6 +195,7 @@ void DflRcclCommSetHalo(DflRcclComm* c, index_type n_local, index_type n_owned, 
     }
 }
 
+void DflRcclCommSetInterior(DflRcclComm* c, index_type n_interior) { c->vt.num_interior_node = n_interior; }
 const DflComm* DflRcclCommVtable(const DflRcclComm* c) { return &c->vt; }
 void DflRcclCommCounters(const DflRcclComm* c, int64_t* n_allreduce, int64_t* n_halo) {
     if (n_allreduce) *n_allreduce = c->n_allreduce;
@@ -178,7 +205,11 @@ void DflRcclCommCounters(const DflRcclComm* c, int64_t* n_allreduce, int64_t* n_
 void DflRcclCommDestroy(DflRcclComm* c) {
     if (!c) return;
     HIPGUARD(hipStreamSynchronize(DflStream()));
+    HIPGUARD(hipStreamSynchronize(c->side));
     if (c->comm) R.CommDestroy(c->comm);
+    HIPGUARD(hipEventDestroy(c->ev_ready));
+    HIPGUARD(hipEventDestroy(c->ev_done));
+    HIPGUARD(hipStreamDestroy(c->side));
     CdamFreeDevice(c->d_send_idx, 0); CdamFreeDevice(c->d_recv_idx, 0);
     CdamFreeDevice(c->d_send, 0); CdamFreeDevice(c->d_recv, 0);
     CdamFreeHost(c->send_count, 0); CdamFreeHost(c->recv_count, 0);

@@ -266,6 +266,12 @@ Matrix* MatrixCreateTypeFS(index_type n_offset, const index_type* offset, void* 
     return m;
 }
 
+void MatrixFSMatVecRange(Matrix* m, value_type* x, value_type* y, index_type row0, index_type row1) {
+    MatrixFS* fs = fs_of(m);
+    ASSERT(fs->block_mode && "MatrixFSMatVecRange needs the block-mode (u,p) matrix");
+    dfl_bcsr_spmv_range(row0, row1, fs->spy1x1->num_row, fs->spy1x1->row_ptr, fs->spy1x1->col_ind, fs->block_val, 1.0, x, 0.0, y,
+                        DflStream());
+}
 void MatrixFSSetOwnedRows(Matrix* m, index_type n) {
     if (m && m->type == MAT_TYPE_FS) fs_of(m)->owned_rows = n;
 }

@@ -280,7 +280,11 @@ value_type* MatrixFSBlockValues(Matrix* matrix); /* NULL unless block mode */
 void MatrixFSExportSubmatrices(Matrix* matrix);
 void MatrixFSImportSubmatrices(Matrix* matrix);
 /* element-partitioned runs: local nodes are numbered owned-first; rows >= n are ghost rows */
+/* y[rows row0..row1) of the (u,p) block system] = A x on those node rows only (block mode) */
+void MatrixFSMatVecRange(Matrix* m, value_type* x, value_type* y, index_type row0, index_type row1);
 void MatrixFSSetOwnedRows(Matrix* matrix, index_type n);
+/* y = A x on node rows [row0, row1) of the block-mode (u,p) system only */
+void MatrixFSMatVecRange(Matrix* matrix, value_type* x, value_type* y, index_type row0, index_type row1);
 index_type MatrixFSOwnedRows(Matrix* matrix);
 /* recursive coordinate bisection of tet centroids into num_part parts (the reference's METIS
  * wrapper, src/partition.c:16-77, is dead code and METIS is unavailable): epart[T] on the host */
@@ -375,6 +379,13 @@ typedef struct DflComm {
     void (*halo_exchange)(void* ctx, f64* d_x);                /* fill ghost entries of a [u|p|..] vector */
     void* ctx;
     index_type num_owned_node; /* dots / norms run over owned nodes only */
+    /* optional split exchange: halo_begin starts filling the ghost entries of d_x asynchronously (the caller has
+     * finished writing d_x on the library stream), halo_end makes the library stream wait for it.  With
+     * num_interior_node > 0 (owned nodes [0, num_interior_node) have no ghost neighbour) the Krylov matvec runs the
+     * interior rows between the two.  NULL / 0: halo_exchange before the whole matvec. */
+    void (*halo_begin)(void* ctx, f64* d_x);
+    void (*halo_end)(void* ctx, f64* d_x);
+    index_type num_interior_node;
 } DflComm;
 void KrylovSetComm(Krylov* krylov, const DflComm* comm);
 const DflComm* KrylovGetComm(const Krylov* krylov); /* NULL on a single GPU */
@@ -388,6 +399,7 @@ int DflRcclLoad(const char* path);
 int DflRcclUniqueIdBytes(void);
 int DflRcclGetUniqueId(char* out_bytes);
 DflRcclComm* DflRcclCommCreate(const char* id_bytes, int rank, int world);
+void DflRcclCommSetInterior(DflRcclComm* c, index_type n_interior); /* owned nodes [0, n_interior) touch no ghost */
 void DflRcclCommSetHalo(DflRcclComm* c, index_type n_local, index_type n_owned, const index_type* send_count,
                         const index_type* send_idx, const index_type* recv_count, const index_type* recv_idx);
 const DflComm* DflRcclCommVtable(const DflRcclComm* c);

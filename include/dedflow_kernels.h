@@ -91,6 +91,9 @@ void dfl_bcsr_spmv(dfl_index N, const dfl_index* row_ptr, const dfl_index* col_i
  * computed; x / y keep the local layout with N = owned + ghost nodes */
 void dfl_bcsr_spmv_rows(dfl_index nrows, dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val,
                         dfl_value alpha, const dfl_value* x, dfl_value beta, dfl_value* y, void* stream);
+/* node rows [row0, row1) only (interior / boundary split that overlaps the halo exchange with the matvec) */
+void dfl_bcsr_spmv_range(dfl_index row0, dfl_index row1, dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind,
+                         const dfl_value* val, dfl_value alpha, const dfl_value* x, dfl_value beta, dfl_value* y, void* stream);
 void dfl_pc_jacobi_setup_rows(dfl_index nrows, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val,
                               dfl_value* dinv33, dfl_value* dinv1, void* stream);
 void dfl_pc_jacobi_apply_rows(dfl_index nrows, dfl_index N, dfl_index n, const dfl_value* dinv33, const dfl_value* dinv1,
