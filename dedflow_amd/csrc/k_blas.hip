@@ -228,8 +228,11 @@ __device__ void drotg_dev(double* a, double* b, double* c, double* s) {
     *a = r; *b = z;
 }
 
-__global__ void gmres_givens_kernel(I iter, const T* d_nrm, T* H, I ldh, T* gv, T* beta, T* res_hist) {
+// SQUARED: *d_nrm holds the (all-reduced) squared norm; it is replaced by its square root first
+template <bool SQUARED>
+__global__ void gmres_givens_kernel(I iter, T* d_nrm, T* H, I ldh, T* gv, T* beta, T* res_hist) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (SQUARED) d_nrm[0] = sqrt(d_nrm[0]);
     T* col = H + (long long)iter * ldh;
     col[iter + 1] = d_nrm[0];  // H[iter+1, iter] = ||w||, krylov.c:228-230
     for (I i = 0; i < iter; ++i) {  // cublasDrot(n=1), krylov.c:258-263
@@ -376,7 +379,11 @@ void dfl_gemv_n(I n, I ncol, const T* Q, int64_t ldq, const T* d_c, T* y, void* 
 }
 
 void dfl_gmres_givens(I iter, const T* d_nrm, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, void* stream) {
-    gmres_givens_kernel<<<1, 64, 0, S(stream)>>>(iter, d_nrm, d_H, ldh, d_gv, d_beta, d_res_hist);
+    gmres_givens_kernel<false><<<1, 64, 0, S(stream)>>>(iter, const_cast<T*>(d_nrm), d_H, ldh, d_gv, d_beta, d_res_hist);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_gmres_givens_sq(I iter, T* d_nrm_sq, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, void* stream) {
+    gmres_givens_kernel<true><<<1, 64, 0, S(stream)>>>(iter, d_nrm_sq, d_H, ldh, d_gv, d_beta, d_res_hist);
     DFL_LAUNCH_CHECK();
 }
 void dfl_gmres_trsv(I m, const T* d_H, I ldh, T* d_beta, void* stream) {

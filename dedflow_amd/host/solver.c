@@ -375,12 +375,13 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
         if (dist) ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 1);
         DFL_TIMED(DFL_TAG_CGS_UPDATE,
                   dfl_cgs_update(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), ex->nrm + iter + 1, dist ? 0 : 1, ex->work, s));
+        /* 4. Givens rotations + residual recurrence, on the device */
         if (dist) {
             ex->comm.allreduce_sum(ex->comm.ctx, ex->nrm + iter + 1, 1);
-            dfl_dsqrt_dev(ex->nrm + iter + 1, s);
+            dfl_gmres_givens_sq(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, ex->res_hist, s);
+        } else {
+            dfl_gmres_givens(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, ex->res_hist, s);
         }
-        /* 4. Givens rotations + residual recurrence, on the device */
-        dfl_gmres_givens(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, ex->res_hist, s);
         if ((iter + 1) % ex->check_interval == 0) {
             HIPGUARD(hipMemcpyAsync(&rnrm, ex->beta + iter + 1, sizeof(f64), D2H, s));
             HIPGUARD(hipStreamSynchronize(s));

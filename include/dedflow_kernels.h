@@ -79,6 +79,9 @@ void dfl_gemv_n(dfl_index n, dfl_index ncol, const dfl_value* Q, int64_t ldq, co
  * d_res_hist[iter] = |beta[iter+1]|. */
 void dfl_gmres_givens(dfl_index iter, const dfl_value* d_nrm, dfl_value* d_H, dfl_index ldh, dfl_value* d_gv,
                       dfl_value* d_beta, dfl_value* d_res_hist, void* stream);
+/* same, for partitioned runs: *d_nrm_sq holds the all-reduced squared norm and is replaced by its square root first */
+void dfl_gmres_givens_sq(dfl_index iter, dfl_value* d_nrm_sq, dfl_value* d_H, dfl_index ldh, dfl_value* d_gv,
+                         dfl_value* d_beta, dfl_value* d_res_hist, void* stream);
 /* back substitution H[0:m,0:m] y = beta[0:m] in place on beta (cublasDtrsv, krylov.c:297-301) */
 void dfl_gmres_trsv(dfl_index m, const dfl_value* d_H, dfl_index ldh, dfl_value* d_beta, void* stream);
 void GMRESResidualUpdatePrivate(dfl_value* beta, dfl_value* gv); /* same symbol as krylov_util.cu:22-24 */
