@@ -595,11 +595,14 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_patch_kernel(const I* __restrict
                                                             const unsigned short* __restrict__ adj,
                                                             const unsigned short* __restrict__ adj_start,
                                                             const I* __restrict__ epos, const T* __restrict__ egeo_b,
-                                                            const T* __restrict__ nodep, T* __restrict__ partial) {
+                                                            const T* __restrict__ nodep, T* __restrict__ partial, I P, int xcd) {
     __shared__ double s_rec[RP_MAXN][NV + 1];
     __shared__ double s_out[RP_MAXT * 4][6 + 1];
     const int t = threadIdx.x;
-    const int pid = blockIdx.x;
+    // XCD-aware order (see tet_lhs_rowpatch_kernel): neighbouring patches share node records -> same L2
+    const int per = (P + 7) >> 3;
+    const int pid = xcd ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+    if (pid >= P) return;
     const int e0 = p_eoff[pid], ne = p_eoff[pid + 1] - e0;
     const int n0 = p_noff[pid], nn = p_noff[pid + 1] - n0;
     const int a = t & 3;
@@ -1151,8 +1154,8 @@ void dfl_assemble_tet_rhs_patch(I npatch, const I* p_eoff, const I* p_noff, cons
                                  const unsigned short* adj, const unsigned short* adj_start, const I* epos, const T* egeo_b,
                                  const T* nodep, T* partial, void* stream) {
     if (npatch <= 0) return;
-    tet_rhs_patch_kernel<<<npatch, RBLK, 0, S(stream)>>>(p_eoff, p_noff, pnode, lien, adj, adj_start, epos, egeo_b, nodep,
-                                                         partial);
+    tet_rhs_patch_kernel<<<8 * ((npatch + 7) / 8), RBLK, 0, S(stream)>>>(p_eoff, p_noff, pnode, lien, adj, adj_start, epos, egeo_b,
+                                                                          nodep, partial, npatch, (g_patch_dbg & 32) ? 0 : 1);
     DFL_LAUNCH_CHECK();
 }
 

@@ -26,11 +26,18 @@ __device__ __forceinline__ d2v ld_val(const d2v* p) {
 
 // U nodal nonzeros per loop trip: all U index loads, then all U value loads, then the 2U
 // gathers are issued before the first FMA -- more bytes in flight per 8-lane row group
-template <bool BETA0, bool NT, int U>
+template <bool BETA0, bool NT, int U, bool XCD = false>
 __global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I row0, I nrows, I N, const I* __restrict__ rp, const I* __restrict__ ci,
                                                        const T* __restrict__ val, T alpha, const T* __restrict__ x, T beta,
                                                        T* __restrict__ y) {
-    const long long gid = (long long)blockIdx.x * BLK + threadIdx.x;
+    // XCD: workgroup b runs on XCD b % 8 (one L2 each); hand every XCD one contiguous slab of rows so that the x
+    // entries shared by neighbouring rows are fetched into ONE L2 instead of up to eight
+    long long blk = blockIdx.x;
+    if (XCD) {
+        const long long per = gridDim.x >> 3;  // grid is a multiple of 8
+        blk = (blk & 7) * per + (blk >> 3);
+    }
+    const long long gid = blk * BLK + threadIdx.x;
     const int row = row0 + (int)(gid >> 3);
     const int l = threadIdx.x & 7;
     if (row >= nrows) return;  // whole 8-lane group leaves together
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I row0, I nrows, I N, co
     }
 }
 
-int g_spmv_variant = 3;
+int g_spmv_variant = 4;
 
 // scalar CSR, 8 lanes per row (reference-layout sub-matrices)
 __global__ __launch_bounds__(BLK) void csr_spmv_kernel(I nrow, const I* __restrict__ rp, const I* __restrict__ ci,
@@ -292,13 +299,15 @@ void dfl_bcsr_spmv_range(I row0, I row1, I N, const I* rp, const I* ci, const T*
     if (row1 <= row0) return;
     const I nrows = row1;
     const int grid = ceil_div((long long)(row1 - row0) * 8, BLK);
+    const int grid8 = (grid + 7) & ~7;
 #define SPMV_LAUNCH(B0, NTV, UV) bcsr_spmv_kernel<B0, NTV, UV><<<grid, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y)
     if (beta == 0.0) {
         switch (g_spmv_variant) {
             case 0: SPMV_LAUNCH(true, false, 2); break;
             case 1: SPMV_LAUNCH(true, true, 2); break;
             case 2: SPMV_LAUNCH(true, false, 4); break;
-            default: SPMV_LAUNCH(true, true, 4); break;
+            case 3: SPMV_LAUNCH(true, true, 4); break;
+            default: bcsr_spmv_kernel<true, true, 4, true><<<grid8, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
         }
     } else {
         SPMV_LAUNCH(false, true, 4);
@@ -309,7 +318,7 @@ void dfl_bcsr_spmv_range(I row0, I row1, I N, const I* rp, const I* ci, const T*
 void dfl_bcsr_spmv_rows(I nrows, I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
     dfl_bcsr_spmv_range(0, nrows, N, rp, ci, val, alpha, x, beta, y, stream);
 }
-/* kernel-variant selection for A/B measurements (key 0: block-CSR SpMV variant 0..3) */
+/* kernel-variant selection for A/B measurements (key 0: block-CSR SpMV variant 0..4; 4 = default, XCD-aware row slabs) */
 void dfl_tune(int key, int value) {
     if (key == 0) g_spmv_variant = value;
 }

@@ -8,11 +8,13 @@ from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 119
 cfgs = [(1, 0, 0)] + [(3,) + tuple(int(v) for v in c.split(":")) for c in (sys.argv[2:] or ["64:64"])]
+cfgs = [c if len(c) == 4 else c + (0,) for c in cfgs]
 mesh = kuhn_cube(M, jitter=0.2)
 wg, dwg = synthetic_fields(mesh)
 L = api.lib()
 ref = None
-for mode, leaf, cap in cfgs:
+for mode, leaf, cap, dbg in cfgs:
+    L.dfl_tune_asm(dbg)
     if mode == 3:
         L.DflSetRhsPatchParameters(leaf, cap)
     P = api.Problem(mesh, schedule=mode)
@@ -32,6 +34,6 @@ for mode, leaf, cap in cfgs:
     v = F_d2.numpy()
     if ref is None:
         ref = v
-    print("mode %d leaf %d cap %d: F assembly median %.3f ms (min %.3f)  rel diff vs mode 1: %.2e" %
-          (mode, leaf, cap, float(np.median(res)), min(res), np.abs(v - ref).max() / np.abs(ref).max()), flush=True)
+    print("mode %d leaf %d cap %d dbg %d: F assembly median %.3f ms (min %.3f)  rel diff vs mode 1: %.2e" %
+          (mode, leaf, cap, dbg, float(np.median(res)), min(res), np.abs(v - ref).max() / np.abs(ref).max()), flush=True)
     P.close()

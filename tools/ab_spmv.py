@@ -18,9 +18,10 @@ x = api.DeviceArray.from_numpy(np.random.default_rng(0).normal(size=6 * P.N))
 y = api.DeviceArray(6 * P.N)
 nbytes = 132.0 * P.nnz1 + 4.0 * (P.N + 1) + 64.0 * P.N
 t = api.Timer()
-res = {v: [] for v in range(4)}
+NV = 5
+res = {v: [] for v in range(NV)}
 for rep in range(6):
-    for v in range(4):
+    for v in range(NV):
         L.dfl_tune(0, v)
         P.matvec(x, y)
         t.start()
@@ -28,7 +29,7 @@ for rep in range(6):
             P.matvec(x, y)
         t.stop()
         res[v].append(t.ms() / 10)
-for v in range(4):
+for v in range(NV):
     a = np.array(res[v][1:])
     print("variant %d (NT=%d U=%d): median %.4f ms  min %.4f  -> %.0f GB/s (%.3f of 8 TB/s)" %
-          (v, v & 1, 2 if v < 2 else 4, np.median(a), a.min(), nbytes / np.median(a) / 1e6, nbytes / np.median(a) / 1e6 / 8000))
+          (v, 1 if v == 4 else v & 1, 2 if v < 2 else 4, np.median(a), a.min(), nbytes / np.median(a) / 1e6, nbytes / np.median(a) / 1e6 / 8000))
