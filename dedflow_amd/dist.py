@@ -254,6 +254,34 @@ class TorchDeviceAllocator:
         return v
 
 
+class RawPointerViews:
+    """torch f64 views of raw device pointers (zero copy, through __cuda_array_interface__): lets the
+    torch.distributed callbacks work on buffers the C layer allocated from its own device pool, so no torch-backed
+    allocator has to be installed.  Same `.tensor()` / `.blocks` surface as TorchDeviceAllocator."""
+
+    class _Raw:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+    def __init__(self, device):
+        import torch
+        self.torch, self.device = torch, device
+        self.blocks = {}   # keeps tensors created by dist_bench.device_vector alive
+        self.bases = []
+        self._views = {}
+
+    def tensor(self, ptr, n, dtype=None):
+        key = (ptr, n)
+        v = self._views.get(key)
+        if v is None:
+            v = self.torch.as_tensor(self._Raw(ptr, n), device=self.device)
+            assert v.data_ptr() == ptr and v.numel() == n
+            if len(self._views) > 4096:
+                self._views.clear()
+            self._views[key] = v
+        return v
+
+
 class DistSolverComm:
     """DflComm callbacks (include/dedflow.h) implemented with torch.distributed."""
 

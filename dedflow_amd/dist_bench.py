@@ -18,7 +18,8 @@ def setup_rank(mesh, rank, world, device, dist, its, staged):
     epart = D.partition_rcb(mesh, world)
     owner = D.node_owner(mesh, epart, world)
     lm = D.build_local(mesh, epart, owner, rank, world)
-    alloc = D.TorchDeviceAllocator(device)           # before any C-side device allocation
+    # device buffers stay in the C layer's own pool (host/runtime.c); the torch.distributed fallback views them by pointer
+    alloc = D.TorchDeviceAllocator(device) if os.environ.get("DFL_TORCH_ALLOCATOR") == "1" else D.RawPointerViews(device)
     P = api.Problem(lm.mesh, maxit=its, atol=0.0, rtol=0.0, quiet=True)
     L = api.lib()
     L.MatrixFSSetOwnedRows.argtypes = [C.c_void_p, C.c_int32]
@@ -43,7 +44,7 @@ def setup_rank(mesh, rank, world, device, dist, its, staged):
 
 
 def device_vector(alloc, torch, device, n, init=None):
-    """f64 device vector living in the torch-backed allocator (so comm callbacks can view it)."""
+    """f64 device vector owned by torch (kept alive in alloc.blocks; comm callbacks view it by pointer)."""
     t = torch.zeros(8 * n + 16, dtype=torch.uint8, device=device)
     p = t.data_ptr()
     alloc.blocks[p] = t

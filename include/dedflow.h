@@ -425,6 +425,8 @@ index_type DflTimeStep(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* 
 /* the assembly caches J^-1-derived element geometry per mesh (the reference recomputes it every call); after writing new
  * node coordinates into Mesh3DDevice(mesh)->xg call this once so the next assembly rebuilds the cache */
 void DflMeshGeometryChanged(Mesh3D* mesh);
+/* device memory pool of the default DEVICE allocator (host/runtime.c; DFL_DEVICE_POOL_GB=0 disables it) */
+void DflDevicePoolStats(int64_t* reserved_bytes, int64_t* in_use_bytes);
 void DflSetQuiet(b32 quiet); /* suppress the reference's stdout chatter ("Assemble: F J", timers) */
 /* which conflict-free launches the assembly kernels execute (set BEFORE Mesh3DGenerateColorBatch):
  *   0  the reference's JPL color batches, one launch per color (reference summation order)
