@@ -113,3 +113,36 @@ def test_coupled_time_step(api, oracle_lib):
     finally:
         pc.close()
         P.close()
+
+
+def test_device_pool_first_fit_and_coalescing(api):
+    """Large DEVICE allocations of the default allocator come out of the pool reserved at Init (host/runtime.c):
+    zero-filled, first fit, neighbours coalesce on free, small requests bypass the pool."""
+    import ctypes as C
+    L = api.lib()
+    L.ArrayCreateDevice.restype = C.POINTER(api.Array)
+    L.ArrayCreateDevice.argtypes = [C.c_int32]
+    L.ArrayDestroy.argtypes = [C.POINTER(api.Array)]
+    L.DflDevicePoolStats.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+
+    def stats():
+        r, u = C.c_int64(0), C.c_int64(0)
+        L.DflDevicePoolStats(C.byref(r), C.byref(u))
+        return r.value, u.value
+
+    reserved, base = stats()
+    if reserved == 0:
+        pytest.skip("device pool disabled (DFL_DEVICE_POOL_GB=0)")
+    n = 4 << 20                                   # 32 MiB of f64 each
+    a, b, c = (L.ArrayCreateDevice(n) for _ in range(3))
+    pa, pb, pc = (C.cast(v.contents.data, C.c_void_p).value for v in (a, b, c))
+    assert stats()[1] == base + 3 * 8 * n and pb == pa + 8 * n and pc == pb + 8 * n
+    assert not api.DeviceArray(n, np.float64, ptr=pb, owner=False).numpy().any()      # zero-filled
+    small = L.ArrayCreateDevice(1000)             # below the pool threshold: plain hipMalloc
+    assert stats()[1] == base + 3 * 8 * n
+    L.ArrayDestroy(a); L.ArrayDestroy(b)          # two neighbours -> one free block of 64 MiB
+    assert stats()[1] == base + 8 * n
+    d = L.ArrayCreateDevice(2 * n)
+    assert C.cast(d.contents.data, C.c_void_p).value == pa
+    L.ArrayDestroy(d); L.ArrayDestroy(c); L.ArrayDestroy(small)
+    assert stats() == (reserved, base)
