@@ -249,6 +249,32 @@ __global__ void gmres_givens_kernel(I iter, T* d_nrm, T* H, I ldh, T* gv, T* bet
     if (res_hist) res_hist[iter] = fabs(beta[iter + 1]);
 }
 
+// second stage of ||w||^2 (partials of cgs_update_kernel, same fixed order as reduce_stage2) + square root + the Givens
+// step in one launch: one kernel boundary less per Arnoldi step
+__global__ __launch_bounds__(BLK) void norm_givens_kernel(int npart, const T* part, T* d_nrm, I iter, T* H, I ldh, T* gv, T* beta,
+                                                         T* res_hist) {
+    __shared__ double lds[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < npart; i += BLK) acc += part[i];
+    const double r = block_sum_256(acc, lds);
+    if (threadIdx.x != 0) return;
+    d_nrm[0] = sqrt(r);
+    T* col = H + (long long)iter * ldh;
+    col[iter + 1] = d_nrm[0];
+    for (I i = 0; i < iter; ++i) {
+        double c = gv[2 * i], s = gv[2 * i + 1];
+        double x = col[i], y = col[i + 1];
+        col[i] = c * x + s * y;
+        col[i + 1] = c * y - s * x;
+    }
+    drotg_dev(&col[iter], &col[iter + 1], &gv[2 * iter], &gv[2 * iter + 1]);
+    col[iter + 1] = 0.0;
+    double b0 = beta[iter];
+    beta[iter + 1] = -gv[2 * iter + 1] * b0;
+    beta[iter] = b0 * gv[2 * iter];
+    if (res_hist) res_hist[iter] = fabs(beta[iter + 1]);
+}
+
 __global__ void gmres_trsv_kernel(I m, const T* H, I ldh, T* beta) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (I i = m - 1; i >= 0; --i) {
@@ -366,6 +392,13 @@ void dfl_cgs_update(I n, I ncol, const T* Q, int64_t ldq, const T* d_h, T* w, T*
         if (take_sqrt) reduce_stage2<true><<<1, BLK, 0, S(stream)>>>(g, work, d_nrm);
         else reduce_stage2<false><<<1, BLK, 0, S(stream)>>>(g, work, d_nrm);
     }
+    DFL_LAUNCH_CHECK();
+}
+void dfl_cgs_update_givens(I n, I ncol, const T* Q, int64_t ldq, const T* d_h, T* w, T* d_nrm, T* work, I iter, T* d_H, I ldh,
+                           T* d_gv, T* d_beta, T* d_res_hist, void* stream) {
+    int g = ceil_div(n, UROWS);
+    cgs_update_kernel<true><<<g, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, d_h, w, work);
+    norm_givens_kernel<<<1, BLK, 0, S(stream)>>>(g, work, d_nrm, iter, d_H, ldh, d_gv, d_beta, d_res_hist);
     DFL_LAUNCH_CHECK();
 }
 void dfl_dsqrt_dev(T* d_val, void* stream) {

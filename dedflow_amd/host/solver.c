@@ -373,14 +373,15 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
         /* 3. classical Gram-Schmidt */
         DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 1, Q, na, QCOL(iter + 1), HCOL(iter), ex->work, s));
         if (dist) ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 1);
-        DFL_TIMED(DFL_TAG_CGS_UPDATE,
-                  dfl_cgs_update(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), ex->nrm + iter + 1, dist ? 0 : 1, ex->work, s));
         /* 4. Givens rotations + residual recurrence, on the device */
         if (dist) {
+            DFL_TIMED(DFL_TAG_CGS_UPDATE,
+                      dfl_cgs_update(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), ex->nrm + iter + 1, 0, ex->work, s));
             ex->comm.allreduce_sum(ex->comm.ctx, ex->nrm + iter + 1, 1);
             dfl_gmres_givens_sq(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, ex->res_hist, s);
         } else {
-            dfl_gmres_givens(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, ex->res_hist, s);
+            DFL_TIMED(DFL_TAG_CGS_UPDATE, dfl_cgs_update_givens(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), ex->nrm + iter + 1,
+                                                                ex->work, iter, H, ldh, ex->gv, ex->beta, ex->res_hist, s));
         }
         if ((iter + 1) % ex->check_interval == 0) {
             HIPGUARD(hipMemcpyAsync(&rnrm, ex->beta + iter + 1, sizeof(f64), D2H, s));

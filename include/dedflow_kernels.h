@@ -69,6 +69,11 @@ void dfl_cgs_dots(dfl_index n, dfl_index ncol, const dfl_value* Q, int64_t ldq, 
                   dfl_value* work, void* stream);
 void dfl_cgs_update(dfl_index n, dfl_index ncol, const dfl_value* Q, int64_t ldq, const dfl_value* d_h, dfl_value* w,
                     dfl_value* d_nrm, int take_sqrt, dfl_value* work, void* stream);
+/* dfl_cgs_update (with the square root) followed by the Givens step of column `iter`; the second stage of the norm
+ * and the Givens recurrence share one launch (2 launches instead of 3) */
+void dfl_cgs_update_givens(dfl_index n, dfl_index ncol, const dfl_value* Q, int64_t ldq, const dfl_value* d_h, dfl_value* w,
+                           dfl_value* d_nrm, dfl_value* work, dfl_index iter, dfl_value* d_H, dfl_index ldh, dfl_value* d_gv,
+                           dfl_value* d_beta, dfl_value* d_res_hist, void* stream);
 void dfl_dsqrt_dev(dfl_value* d_val, void* stream); /* *d_val = sqrt(*d_val) */
 /* y = Q[:,0:ncol] c  (cublasDgemv OP_N of krylov.c:304-311) */
 void dfl_gemv_n(dfl_index n, dfl_index ncol, const dfl_value* Q, int64_t ldq, const dfl_value* d_c, dfl_value* y, void* stream);
