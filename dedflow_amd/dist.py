@@ -340,15 +340,20 @@ class RcclSolverComm:
         if L.DflRcclLoad(path.encode()) != 0:
             raise RuntimeError("RCCL could not be loaded from %r" % path)
         nbytes = L.DflRcclUniqueIdBytes()
-        buf = C.create_string_buffer(nbytes)
-        if plan.rank == 0 and L.DflRcclGetUniqueId(buf) != 0:
-            raise RuntimeError("ncclGetUniqueId failed")
-        box = [bytes(buf.raw)]
+        box = [b"", b""]     # two ids: all-reduce communicator, halo communicator (own stream)
+        if plan.rank == 0:
+            for k in range(2):
+                buf = C.create_string_buffer(nbytes)
+                if L.DflRcclGetUniqueId(buf) != 0:
+                    raise RuntimeError("ncclGetUniqueId failed")
+                box[k] = bytes(buf.raw)
         dist.broadcast_object_list(box, src=0)
         torch.cuda.synchronize()
         self.c = L.DflRcclCommCreate(box[0], plan.rank, plan.world)
         if not self.c:
             raise RuntimeError("DflRcclCommCreate failed")
+        L.DflRcclCommCreateHaloComm.restype, L.DflRcclCommCreateHaloComm.argtypes = None, [vp, C.c_char_p]
+        L.DflRcclCommCreateHaloComm(self.c, box[1])
         sc = np.asarray(plan.send_splits, np.int32)
         rc = np.asarray(plan.recv_splits, np.int32)
         si = np.ascontiguousarray(plan.send_all.cpu().numpy().astype(np.int32))

@@ -42,7 +42,9 @@ static struct {
     } while (0)
 
 struct DflRcclComm {
-    rccl_comm comm;
+    rccl_comm comm;      /* all-reduces, on the library stream */
+    rccl_comm halo_comm; /* point-to-point halo traffic; a communicator of its own because it runs on the side stream
+                            concurrently with the library stream (NULL: shares `comm`) */
     int rank, world;
     index_type n_local, n_owned;
     index_type nsend, nrecv;
@@ -101,12 +103,13 @@ static void rccl_allreduce(void* ctx, f64* d_buf, index_type n) {
 
 static void rccl_halo_on(DflRcclComm* c, f64* d_x, hipStream_t s) {
     if (c->nsend == 0 && c->nrecv == 0) return;
+    rccl_comm hc = c->halo_comm ? c->halo_comm : c->comm;
     dfl_gather_idx(c->nsend, c->d_send_idx, d_x, c->d_send, s);
     RCCLGUARD(R.GroupStart());
     index_type so = 0, ro = 0;
     for (int q = 0; q < c->world; ++q) {
-        if (c->send_count[q]) RCCLGUARD(R.Send(c->d_send + so, (size_t)c->send_count[q], RCCL_FLOAT64, q, c->comm, s));
-        if (c->recv_count[q]) RCCLGUARD(R.Recv(c->d_recv + ro, (size_t)c->recv_count[q], RCCL_FLOAT64, q, c->comm, s));
+        if (c->send_count[q]) RCCLGUARD(R.Send(c->d_send + so, (size_t)c->send_count[q], RCCL_FLOAT64, q, hc, s));
+        if (c->recv_count[q]) RCCLGUARD(R.Recv(c->d_recv + ro, (size_t)c->recv_count[q], RCCL_FLOAT64, q, hc, s));
         so += c->send_count[q];
         ro += c->recv_count[q];
     }
@@ -164,6 +167,13 @@ DflRcclComm* DflRcclCommCreate(const char* id128, int rank, int world) {
     return c;
 }
 
+/* optional second communicator for the halo traffic (collective; every rank passes the same second id) */
+void DflRcclCommCreateHaloComm(DflRcclComm* c, const char* id128) {
+    rccl_unique_id id;
+    memcpy(&id, id128, sizeof id);
+    RCCLGUARD(R.CommInitRank(&c->halo_comm, c->world, id, c->rank));
+}
+
 /* halo plan: send_idx / recv_idx are HOST arrays of flat dof indices into the local [u|p|..] vector,
  * concatenated in rank order; send_count / recv_count [world] give each rank's share */
 void DflRcclCommSetHalo(DflRcclComm* c, index_type n_local, index_type n_owned, const index_type* send_count,
@@ -206,6 +216,7 @@ void DflRcclCommDestroy(DflRcclComm* c) {
     if (!c) return;
     HIPGUARD(hipStreamSynchronize(DflStream()));
     HIPGUARD(hipStreamSynchronize(c->side));
+    if (c->halo_comm) R.CommDestroy(c->halo_comm);
     if (c->comm) R.CommDestroy(c->comm);
     HIPGUARD(hipEventDestroy(c->ev_ready));
     HIPGUARD(hipEventDestroy(c->ev_done));

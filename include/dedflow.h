@@ -393,12 +393,13 @@ const DflComm* KrylovGetComm(const Krylov* krylov); /* NULL on a single GPU */
 /* RCCL implementation of DflComm (host/comm_rccl.c): collectives enqueued from C on the library stream.
  * Bootstrap: every rank DflRcclLoad(path to librccl.so, NULL/"" = "librccl.so.1"); rank 0 DflRcclGetUniqueId and
  * broadcasts the DflRcclUniqueIdBytes() bytes (MPI, torch.distributed, a file ...); all ranks DflRcclCommCreate
- * (collective), DflRcclCommSetHalo with their halo plan, KrylovSetComm(ksp, DflRcclCommVtable(c)). */
+ * (collective), optionally DflRcclCommCreateHaloComm with a second broadcast id, DflRcclCommSetHalo with their halo plan, KrylovSetComm(ksp, DflRcclCommVtable(c)). */
 typedef struct DflRcclComm DflRcclComm;
 int DflRcclLoad(const char* path);
 int DflRcclUniqueIdBytes(void);
 int DflRcclGetUniqueId(char* out_bytes);
 DflRcclComm* DflRcclCommCreate(const char* id_bytes, int rank, int world);
+void DflRcclCommCreateHaloComm(DflRcclComm* c, const char* id_bytes); /* optional own communicator for the halo stream */
 void DflRcclCommSetInterior(DflRcclComm* c, index_type n_interior); /* owned nodes [0, n_interior) touch no ghost */
 void DflRcclCommSetHalo(DflRcclComm* c, index_type n_local, index_type n_owned, const index_type* send_count,
                         const index_type* send_idx, const index_type* recv_count, const index_type* recv_idx);
