@@ -133,8 +133,31 @@ color_t GetMaxColor(const color_t* color, index_type n) {
     return mc;
 }
 
+/* connectivity sanity before any kernel indexes node arrays with it (an out-of-range vertex id would be a device fault,
+ * a degenerate tet a division by zero in the geometry): host pass over the host copy, once per coloring */
+static void mesh_validate(const Mesh3D* mesh) {
+    const Mesh3DData* h = mesh->host;
+    if (!h || !h->ien) return;
+    const index_type N = mesh->num_node, T = mesh->num_tet;
+    for (index_type e = 0; e < T; ++e) {
+        const index_type* nd = h->ien + (size_t)e * 4;
+        for (int a = 0; a < 4; ++a)
+            if (nd[a] < 0 || nd[a] >= N) {
+                fprintf(stderr, "dedflow: tet %d has vertex id %d outside [0, %d)\n", (int)e, (int)nd[a], (int)N);
+                ASSERT(FALSE && "mesh connectivity out of range");
+                abort();
+            }
+        if (nd[0] == nd[1] || nd[0] == nd[2] || nd[0] == nd[3] || nd[1] == nd[2] || nd[1] == nd[3] || nd[2] == nd[3]) {
+            fprintf(stderr, "dedflow: tet %d repeats a vertex (%d %d %d %d)\n", (int)e, (int)nd[0], (int)nd[1], (int)nd[2], (int)nd[3]);
+            ASSERT(FALSE && "degenerate tet");
+            abort();
+        }
+    }
+}
+
 void Mesh3DColor(Mesh3D* mesh) {
     index_type T = mesh->num_tet;
+    mesh_validate(mesh);
     if (!mesh->color) mesh->color = (color_t*)CdamMallocDevice((ptrdiff_t)T * SIZE_OF(color_t));
     ColorMeshTet(mesh, MAX_COLOR, mesh->color);
     mesh->num_color = GetMaxColor(mesh->color, T) + 1;

@@ -353,6 +353,11 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     ex->stats.converged = FALSE;
     if (ex->verbose)
         fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", 0, rnrm_init, atol, 1.0, rtol);
+    if (rnrm_init == 0.0) { /* x already solves the system: the reference would normalise by zero here (krylov.c:130) */
+        ex->stats.iterations = 0;
+        ex->stats.converged = TRUE;
+        return;
+    }
 
     /* the normalisation of Q[:,k] is folded into the preconditioner application that consumes it;
        nrm[k] holds the norm Q[:,k] still has to be divided by */
@@ -453,6 +458,7 @@ static void CGSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     r0 = sqrt(h[1]);
     ex->stats.rnrm_init = r0;
     if (ex->verbose) fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", 0, r0, ksp->atol, 1.0, ksp->rtol);
+    if (r0 == 0.0) converged = TRUE; /* x already solves the system: alpha would be 0/0 */
     while (!converged && it < maxit) {
         if (dist) ex->comm.halo_exchange(ex->comm.ctx, p);
         MatrixMatVec(A, p, Ap);

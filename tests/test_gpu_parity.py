@@ -387,6 +387,23 @@ def test_geometry_cache_follows_moved_nodes(api, oracle_lib):
         P.close()
 
 
+def test_krylov_zero_rhs_returns_immediately(api):
+    """b = 0, x0 = 0: the initial residual is exactly zero; the solve returns converged with 0 iterations and x stays 0
+    (the reference would divide by the zero norm at krylov.c:130 -- deliberate guard)."""
+    m = kuhn_cube(4, jitter=0.2)
+    wg, dwg = synthetic_fields(m)
+    P = api.Problem(m, maxit=30)
+    try:
+        wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+        P.assemble_system(wg_d, dwg_d, None, want_J=True)
+        x_d, b_d = api.DeviceArray(6 * P.N), api.DeviceArray(6 * P.N)
+        it, r0, hist, conv = P.solve(x_d, b_d)
+        api.sync()
+        assert it == 0 and r0 == 0.0 and conv and not x_d.numpy().any()
+    finally:
+        P.close()
+
+
 def test_single_tet_all_faces(api, oracle_lib):
     """DBG_TET-like case (src/main.c:357-361): one element, face assembly on a chosen group."""
     m = single_tet()
