@@ -1,0 +1,58 @@
+"""Probe: compute time of ONE rank's share of the 10M-tet step at an 8-way partition (rank 0's local mesh incl. its halo
+layer), run through the partitioned code path (owned rows, interior/boundary split, RCCL communicator of world size 1 with
+an empty halo plan).  No inter-GPU latency is in it: t_1gpu / this = the ceiling of the 8-GPU strong-scaling factor.
+Launch: python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 tools/probe_rank_local.py [M] [parts]"""
+import sys, os, time, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.distributed as dist
+from dedflow_amd import api, dist as D, dist_bench
+from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 119
+parts = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+its = 40
+torch.cuda.set_device(0)
+device = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+mesh = kuhn_cube(M, jitter=0.2)
+wg, dwg = synthetic_fields(mesh)
+epart = D.partition_rcb(mesh, parts)
+owner = D.node_owner(mesh, epart, parts)
+for r in (0, parts // 2):
+    lm = D.build_local(mesh, epart, owner, r, parts)
+    P = api.Problem(lm.mesh, maxit=its, atol=0.0, rtol=0.0, quiet=True)
+    L = api.lib()
+    L.MatrixFSSetOwnedRows.argtypes = [C.c_void_p, C.c_int32]
+    L.MatrixFSSetOwnedRows(C.cast(P.J, C.c_void_p), lm.n_owned)
+
+    class Plan:   # empty halo plan on a 1-rank communicator, real owned / interior counts
+        rank, world = 0, 1
+        n_local, n_owned, n_interior = lm.l2g_node.size, lm.n_owned, lm.n_interior
+        send_splits, recv_splits = [0], [0]
+        send_all = torch.zeros(0, dtype=torch.int64, device=device)
+        recv_all = torch.zeros(0, dtype=torch.int64, device=device)
+        def exchange(self, x): pass
+    comm = D.RcclSolverComm(Plan(), dist, device)
+    comm.install(P.ksp)
+    alloc = D.RawPointerViews(device)
+    n, no, Ng = P.N, lm.n_owned, mesh.num_node
+    wg_t, wg_p = dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(wg, lm, Ng))
+    dwg_t, dwg_p = dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(dwg, lm, Ng))
+    F_t, F_p = dist_bench.device_vector(alloc, torch, device, 6 * n)
+    x_t, x_p = dist_bench.device_vector(alloc, torch, device, 6 * n)
+    Pp = dist_bench._Ptr
+    def step():
+        P.assemble_system(Pp(wg_p), Pp(dwg_p), Pp(F_p), want_J=False)
+        P.assemble_system(Pp(wg_p), Pp(dwg_p), None, want_J=True)
+        F_t[3 * no:3 * n].zero_(); F_t[3 * n + no:4 * n].zero_(); x_t.zero_()
+        return P.solve(Pp(x_p), Pp(F_p))
+    for _ in range(2): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    K = 5
+    for _ in range(K): step()
+    torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0) / K
+    print("rank %d of %d: %d local tets (%d owned nodes, %d interior), %d collectives/step on a 1-rank communicator: %.2f ms per step"
+          % (r, parts, P.T, no, lm.n_interior, (comm.n_allreduce + comm.n_halo) // (K + 2), ms), flush=True)
+    P.close()
+dist.destroy_process_group()
