@@ -273,11 +273,11 @@ def main():
         "assemble_F_dofs_per_s": (6.0 * N / (tF * 1e-3)) if tF else None,
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "dem_sweep": dem,
         "spmv_back_to_back_ms": spmv_grouped_ms,
-        # the whole Krylov solve against the HBM roofline: algorithmic bytes of its (its+1) matvecs, its CGS steps, its+1
-        # preconditioner applications and the final basis combination over the un-instrumented solve time
+        # the whole Krylov solve against the HBM roofline: algorithmic bytes of its `its` matvecs (x0 = 0: r0 = b needs none),
+        # its CGS steps, its+1 preconditioner applications and the final basis combination over the un-instrumented solve time
         "krylov_solve": (lambda b: {"ms": solve_ms_timed, "algorithmic_GB": b / 1e9, "GBps": b / (solve_ms_timed * 1e-3) / 1e9,
                                     "frac_of_8TBps": b / (solve_ms_timed * 1e-3) / 1e9 / HBM_PEAK_GBS})(
-            (its + 1) * ab["spmv"] + sum(ab["cgs"]) + (its + 1) * ab["pc_apply"] + 8.0 * 4 * N * (its + 2)),
+            its * ab["spmv"] + sum(ab["cgs"]) + (its + 1) * ab["pc_apply"] + 8.0 * 4 * N * (its + 2)),
         "setup_s": t_setup, "gmres_residual_drop": float(hist[-1] / r0) if len(hist) else None,
     }
     print(json.dumps(out))

@@ -276,15 +276,19 @@ static void ws_ensure(KrylovExt* x, index_type n, index_type maxit, index_type l
     x->ws_maxit = maxit;
 }
 
-/* is the [4N, n) tail of a device vector identically zero?  (one reduction, one 8-byte read) */
-static b32 tail_is_zero(KrylovExt* x, const f64* v, index_type begin, index_type n, f64* scratch2) {
-    if (n <= begin) return TRUE;
-    f64 h = 0.0;
-    dfl_dnrm2(n - begin, v + begin, scratch2, scratch2 + 8, DflStream());
-    HIPGUARD(hipMemcpyAsync(&h, scratch2, sizeof h, D2H, DflStream()));
-    HIPGUARD(hipStreamSynchronize(DflStream()));
-    UNUSED(x);
-    return h == 0.0;
+/* Two questions about the operands of a solve, answered with one 16-byte read: is the [begin, n) tail of b identically
+ * zero (then the Krylov vectors live on [0, begin), Q5), and is the initial guess x identically zero (then r = b exactly
+ * and the matvec of krylov.c:114 is skipped -- b - A*0 is b bit for bit)? */
+static void probe_operands(const f64* b, index_type begin, index_type n, const f64* x, f64* scratch, b32* tail_zero, b32* x_zero) {
+    f64 h[2] = {1.0, 1.0};
+    hipStream_t s = DflStream();
+    if (n > begin) dfl_dnrm2(n - begin, b + begin, scratch, scratch + 8, s);
+    else HIPGUARD(hipMemsetAsync(scratch, 0, sizeof(f64), s));
+    if (x) dfl_dnrm2(n, x, scratch + 1, scratch + 8, s);
+    HIPGUARD(hipMemcpyAsync(h, scratch, (x ? 2 : 1) * sizeof(f64), D2H, s));
+    HIPGUARD(hipStreamSynchronize(s));
+    *tail_zero = h[0] == 0.0;
+    *x_zero = x ? h[1] == 0.0 : FALSE;
 }
 
 /* z = M^{-1} (w / *d_nrm), q_out = w / *d_nrm   (d_nrm == NULL: no scaling) */
@@ -324,9 +328,13 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     ws_ensure(ex, n, maxit, ldh);
     /* active length: [0,4N) if the matrix is the block-mode (u,p) system and b's tail is zero (Q5) */
     index_type na = n;
-    if (MatrixFSBlockValues(A)) {
-        index_type N = ((MatrixFS*)A->data)->spy1x1->num_row;
-        if (n == 6 * N && tail_is_zero(ex, b, 4 * N, n, ex->work)) na = 4 * N;
+    b32 x_is_zero = FALSE;
+    {
+        b32 tail_zero = FALSE;
+        const b32 up_system = MatrixFSBlockValues(A) && n == 6 * ((MatrixFS*)A->data)->spy1x1->num_row;
+        /* partitioned runs keep the matvec: every rank has to take the same path through the halo exchange */
+        probe_operands(b, up_system ? 4 * (n / 6) : n, n, dist ? NULL : x, ex->work, &tail_zero, &x_is_zero);
+        if (up_system && tail_zero) na = 4 * (n / 6);
     }
     f64* Q = ex->Q;
     f64* H = ex->H;
@@ -340,7 +348,7 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     /* 0. r = b - A x  (krylov.c:112-116) */
     dfl_dcopy(na, b, QCOL(0), s);
     if (dist) ex->comm.halo_exchange(ex->comm.ctx, x);
-    MatrixAMVPBY(A, -1.0, x, 1.0, QCOL(0));
+    if (!x_is_zero) MatrixAMVPBY(A, -1.0, x, 1.0, QCOL(0));
     if (dist) {
         dfl_ddot(na, QCOL(0), QCOL(0), ex->nrm, ex->work, s);
         ex->comm.allreduce_sum(ex->comm.ctx, ex->nrm, 1);
@@ -434,7 +442,9 @@ static void CGSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     ws_ensure(ex, n, 3, 32); /* r, z, p, Ap in Q[0..3] */
     if (MatrixFSBlockValues(A)) {
         index_type N = ((MatrixFS*)A->data)->spy1x1->num_row;
-        if (n == 6 * N && tail_is_zero(ex, b, 4 * N, n, ex->work)) na = 4 * N;
+        b32 tail_zero = FALSE, unused = FALSE;
+        if (n == 6 * N) probe_operands(b, 4 * N, n, NULL, ex->work, &tail_zero, &unused);
+        if (tail_zero) na = 4 * N;
     }
     f64 *r = ex->Q, *z = ex->Q + (size_t)n, *p = ex->Q + 2 * (size_t)n, *Ap = ex->Q + 3 * (size_t)n;
     f64 h[2], rz, rz_new, pAp, rn, r0;
