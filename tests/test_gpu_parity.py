@@ -223,6 +223,23 @@ def test_gmres_matches_oracle(case, api):
     assert np.all(xg[4 * S.N:] == 0.0)
 
 
+def test_gmres_nonzero_initial_guess_matches_oracle(case, api):
+    """x0 != 0 takes the r0 = b - A x0 path (x0 = 0 skips that matvec: r0 = b exactly); both against the oracle."""
+    m, S, P, wg, dwg = case
+    F_d, F, vals = _assembled(case, api)
+    rng = np.random.default_rng(17)
+    x0 = np.zeros(6 * S.N)
+    x0[:4 * S.N] = 1e-3 * rng.normal(size=4 * S.N)
+    x_d = api.DeviceArray.from_numpy(x0)
+    it, r0, hist, conv = P.solve(x_d, F_d)
+    xo, ho, r0o, ito = S.gmres(vals, F, x0=x0)
+    assert it == ito and abs(r0 - r0o) <= 1e-12 * r0o
+    k = np.arange(1, it + 1)
+    assert np.all(np.abs(hist - ho) <= 1e-10 * r0o * np.maximum(1.0, k / 10.0)), np.abs(hist - ho).max() / r0o
+    ok, err = close(x_d.numpy()[:4 * S.N], xo[:4 * S.N], 1e-8)
+    assert ok, f"solution rel err {err:.3e}"
+
+
 @pytest.mark.parametrize("name", ["cube_M4", "cube_M12"])
 def test_golden_fixtures(name, api):
     """HIP path against the committed fixtures only (no oracle call)."""
