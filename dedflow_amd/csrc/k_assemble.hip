@@ -598,10 +598,12 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_patch_kernel(const I* __restrict
                                                             const T* __restrict__ nodep, T* __restrict__ partial, I P, int xcd) {
     __shared__ double s_rec[RP_MAXN][NV + 1];
     __shared__ double s_out[RP_MAXT * 4][6 + 1];
+    __shared__ unsigned short s_adj[RP_MAXT * 4];
+    __shared__ unsigned short s_st[RP_MAXN + 1];
     const int t = threadIdx.x;
     // XCD-aware order (see tet_lhs_rowpatch_kernel): neighbouring patches share node records -> same L2
     const int per = (P + 7) >> 3;
-    const int pid = xcd ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+    const int pid = (xcd & 1) ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
     if (pid >= P) return;
     const int e0 = p_eoff[pid], ne = p_eoff[pid + 1] - e0;
     const int n0 = p_noff[pid], nn = p_noff[pid + 1] - n0;
@@ -615,6 +617,8 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_patch_kernel(const I* __restrict
 #pragma unroll
         for (int k = 0; k < 8; ++k) grec[k] = gp[k];
     }
+    for (int k = t; k < ne * 4; k += RBLK) s_adj[k] = adj[(long long)e0 * 4 + k];
+    for (int k = t; k <= nn; k += RBLK) s_st[k] = adj_start[n0 + pid + k];
     for (int k = t; k < nn * 7; k += RBLK) {
         const int ln = k / 7, part = k - ln * 7;
         const double2 v = reinterpret_cast<const double2*>(nodep + (long long)pnode[n0 + ln] * NREC)[part];
@@ -622,6 +626,7 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_patch_kernel(const I* __restrict
         s_rec[ln][2 * part + 1] = v.y;
     }
     __syncthreads();
+    if (xcd & 64) return;
     for (int le = t >> 2; le < ne; le += REPB) {  // whole quads
         if (le >= REPB) {
             lnv = *reinterpret_cast<const uchar4*>(lien + ((long long)e0 + le) * 4);
@@ -636,13 +641,11 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_patch_kernel(const I* __restrict
         for (int j = 0; j < 6; ++j) s_out[le * 4 + a][j] = mine[j];
     }
     __syncthreads();
-    // ordered sum per patch node: contributions in ascending local tet order
-    const unsigned short* st = adj_start + n0 + pid;
-    const unsigned short* ad = adj + (long long)e0 * 4;
+    // ordered sum per patch node: contributions in ascending local tet order (adjacency staged in LDS above)
     for (int k = t; k < nn * 6; k += RBLK) {
         const int ln = k / 6, j = k - ln * 6;
         double sum = 0.0;
-        for (int q = st[ln]; q < st[ln + 1]; ++q) sum += s_out[ad[q]][j];
+        for (int q = s_st[ln]; q < s_st[ln + 1]; ++q) sum += s_out[s_adj[q]][j];
         partial[(long long)n0 * 6 + k] = sum;
     }
 }
@@ -1155,7 +1158,7 @@ void dfl_assemble_tet_rhs_patch(I npatch, const I* p_eoff, const I* p_noff, cons
                                  const T* nodep, T* partial, void* stream) {
     if (npatch <= 0) return;
     tet_rhs_patch_kernel<<<8 * ((npatch + 7) / 8), RBLK, 0, S(stream)>>>(p_eoff, p_noff, pnode, lien, adj, adj_start, epos, egeo_b,
-                                                                          nodep, partial, npatch, (g_patch_dbg & 32) ? 0 : 1);
+                                                                          nodep, partial, npatch, ((g_patch_dbg & 32) ? 0 : 1) | (g_patch_dbg & (64 | 128)));
     DFL_LAUNCH_CHECK();
 }
 
