@@ -385,23 +385,11 @@ constexpr int FREC = 8;  // packed residual record: F_u0 F_u1 F_u2 F_p F_phi F_T
 // Residual of one tet on 4 lanes (lane a: node a for the result, quadrature point a for the weak form).
 // r[b] = node record of vertex b (x[3] u[3] phi T du[3] p dphi dT, in LDS); result: mine[0..5] = the 6 residual
 // components of node a summed over the 4 quadrature points (DPP quad reduce-scatter).
-template <bool EGEO>
-__device__ __forceinline__ void rhs_quad(const double* const* r, const double* __restrict__ egeo, int a, double* mine) {
+__device__ __forceinline__ void rhs_quad(const double* const* r, int a, double* mine) {
     const int iq = a;
     double shg[12], detJ, gg, itr;
-    if (EGEO) {  // cached geometry record (elem_geometry_kernel): the 4 lanes of an element read the same line
-        const double2* grec = reinterpret_cast<const double2*>(egeo);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const double2 v = grec[k];
-            shg[2 * k] = v.x;
-            shg[2 * k + 1] = v.y;
-        }
-        const double2 v6 = grec[6], v7 = grec[7];
-        detJ = v6.x;
-        gg = v6.y;
-        itr = v7.x;
-    } else {  // from the vertex coordinates in the node records (no extra HBM stream)
+    {  // geometry from the vertex coordinates in the node records (already staged in LDS: no extra HBM stream; the
+       // cached geometry records were measured: equal time with prefetch, slower without, 1.3 GB more traffic)
         double x[12], invJ[9], G[9];
 #pragma unroll
         for (int b = 0; b < 4; ++b)
@@ -573,7 +561,7 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_kernel(I B, const I* __restrict_
     if (!valid) return;  // whole 4-lane groups leave together; shuffles below stay inside a group
     const double* r[4] = {s_n[te][0], s_n[te][1], s_n[te][2], s_n[te][3]};
     double mine[6];
-    rhs_quad<false>(r, nullptr, a, mine);
+    rhs_quad(r, a, mine);
     // ElemRHSLocal2Global: non-atomic, race-free inside a class; one 64-byte record per node
     double2* dst = reinterpret_cast<double2*>(Fp + node * FREC);
     double2 f0 = dst[0], f1 = dst[1], f2 = dst[2];
@@ -594,7 +582,6 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_patch_kernel(const I* __restrict
                                                             const I* __restrict__ pnode, const unsigned char* __restrict__ lien,
                                                             const unsigned short* __restrict__ adj,
                                                             const unsigned short* __restrict__ adj_start,
-                                                            const I* __restrict__ epos, const T* __restrict__ egeo_b,
                                                             const T* __restrict__ nodep, T* __restrict__ partial, I P, int xcd) {
     __shared__ double s_rec[RP_MAXN][NV + 1];
     __shared__ double s_out[RP_MAXT * 4][6 + 1];
@@ -608,15 +595,8 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_patch_kernel(const I* __restrict
     const int e0 = p_eoff[pid], ne = p_eoff[pid + 1] - e0;
     const int n0 = p_noff[pid], nn = p_noff[pid + 1] - n0;
     const int a = t & 3;
-    // this quad's first tet: local vertex ids and geometry record are requested before the node records are staged
     uchar4 lnv = make_uchar4(0, 0, 0, 0);
-    double2 grec[8];
-    if ((t >> 2) < ne) {
-        lnv = *reinterpret_cast<const uchar4*>(lien + ((long long)e0 + (t >> 2)) * 4);
-        const double2* gp = reinterpret_cast<const double2*>(egeo_b + (long long)epos[e0 + (t >> 2)] * 16);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) grec[k] = gp[k];
-    }
+    if ((t >> 2) < ne) lnv = *reinterpret_cast<const uchar4*>(lien + ((long long)e0 + (t >> 2)) * 4);
     for (int k = t; k < ne * 4; k += RBLK) s_adj[k] = adj[(long long)e0 * 4 + k];
     for (int k = t; k <= nn; k += RBLK) s_st[k] = adj_start[n0 + pid + k];
     for (int k = t; k < nn * 7; k += RBLK) {
@@ -628,15 +608,10 @@ __global__ __launch_bounds__(RBLK) void tet_rhs_patch_kernel(const I* __restrict
     __syncthreads();
     if (xcd & 64) return;
     for (int le = t >> 2; le < ne; le += REPB) {  // whole quads
-        if (le >= REPB) {
-            lnv = *reinterpret_cast<const uchar4*>(lien + ((long long)e0 + le) * 4);
-            const double2* gp = reinterpret_cast<const double2*>(egeo_b + (long long)epos[e0 + le] * 16);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) grec[k] = gp[k];
-        }
+        if (le >= REPB) lnv = *reinterpret_cast<const uchar4*>(lien + ((long long)e0 + le) * 4);
         const double* r[4] = {s_rec[lnv.x], s_rec[lnv.y], s_rec[lnv.z], s_rec[lnv.w]};
         double mine[6];
-        rhs_quad<true>(r, reinterpret_cast<const double*>(grec), a, mine);
+        rhs_quad(r, a, mine);
 #pragma unroll
         for (int j = 0; j < 6; ++j) s_out[le * 4 + a][j] = mine[j];
     }
@@ -1154,11 +1129,11 @@ void dfl_assemble_tet_lhs_rowpatch(I npatch, const I* p_ioff, const I* p_soff, c
 }
 
 void dfl_assemble_tet_rhs_patch(I npatch, const I* p_eoff, const I* p_noff, const I* pnode, const unsigned char* lien,
-                                 const unsigned short* adj, const unsigned short* adj_start, const I* epos, const T* egeo_b,
-                                 const T* nodep, T* partial, void* stream) {
+                                 const unsigned short* adj, const unsigned short* adj_start, const T* nodep, T* partial,
+                                 void* stream) {
     if (npatch <= 0) return;
-    tet_rhs_patch_kernel<<<8 * ((npatch + 7) / 8), RBLK, 0, S(stream)>>>(p_eoff, p_noff, pnode, lien, adj, adj_start, epos, egeo_b,
-                                                                          nodep, partial, npatch, ((g_patch_dbg & 32) ? 0 : 1) | (g_patch_dbg & (64 | 128)));
+    tet_rhs_patch_kernel<<<8 * ((npatch + 7) / 8), RBLK, 0, S(stream)>>>(p_eoff, p_noff, pnode, lien, adj, adj_start, nodep,
+                                                                          partial, npatch, ((g_patch_dbg & 32) ? 0 : 1) | (g_patch_dbg & 64));
     DFL_LAUNCH_CHECK();
 }
 

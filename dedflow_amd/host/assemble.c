@@ -84,7 +84,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
     const b32 patch_lhs = J && DflAssemblyScheduleMode() == 2;
     const b32 rowpatch_lhs = J && DflAssemblyScheduleMode() == 3;
     const b32 patch_rhs = F && DflAssemblyScheduleMode() >= 2;
-    if (!x->egeo_b) { /* geometry cache in schedule order (static mesh), built once */
+    if (J && !x->egeo_b) { /* geometry cache in schedule order (static mesh), built once; the LHS kernels read it */
         x->egeo_b = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
         dfl_elem_geometry(mesh->num_tet, x->ien_b, dev->xg, x->egeo_b, s);
     }
@@ -136,7 +136,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
         const RhsPatchSched* rp = x->rhspatch;
         int slot = DflProfileBegin(DFL_TAG_ASM_RHS);
         dfl_assemble_tet_rhs_patch(rp->num_patch, rp->d_eoff, rp->d_noff, rp->d_pnode, rp->d_lien, rp->d_adj, rp->d_adj_start,
-                                   rp->d_epos, x->egeo_b, x->nodep, rp->d_partial, s);
+                                   x->nodep, rp->d_partial, s);
         dfl_rhs_node_sum(N, rp->d_goff, rp->d_gidx, rp->d_partial, F, s);
         DflProfileEnd(slot);
     } else if (F) {

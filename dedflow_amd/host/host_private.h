@@ -30,7 +30,6 @@ typedef struct RhsPatchSched {
     u8* d_lien;              /* device [T][4] local (patch) node index of each tet vertex */
     uint16_t* d_adj;         /* device [4T] per patch: (local tet)*4 + a grouped by patch node, ascending tet */
     uint16_t* d_adj_start;   /* device [total_nodes + P] per patch nn+1 group starts */
-    index_type* d_epos;      /* device [T] execution-schedule position of each patch-ordered tet */
     index_type* d_goff;      /* device [N+1] node -> range of gidx */
     index_type* d_gidx;      /* device [total_nodes] partial record ids of each node, ascending patch */
     f64* d_partial;          /* device [total_nodes][6] */

@@ -405,14 +405,6 @@ RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_typ
                 adj[(size_t)eoff[p] * 4 + cur[l]++] = (uint16_t)(k * 4 + a);
             }
     }
-    /* position of every patch-ordered tet in the execution schedule (indexes the geometry cache egeo_b) */
-    const index_type* sched_elem = ((MeshExt*)mesh->ext)->h_sched_elem;
-    ASSERT(sched_elem && "Mesh3DGenerateColorBatch must run before the RHS patch schedule is built");
-    index_type* pos_of = (index_type*)malloc(sizeof(index_type) * (size_t)T);
-    for (index_type q = 0; q < T; ++q) pos_of[sched_elem[q]] = q;
-    index_type* ien_p = (index_type*)malloc(sizeof(index_type) * (size_t)T); /* reused name: epos */
-    for (index_type q = 0; q < T; ++q) ien_p[q] = pos_of[idx[q]];
-    free(pos_of);
     /* node -> its partial records (ascending patch order) */
     index_type* goff = (index_type*)calloc((size_t)N + 1, sizeof(index_type));
     for (int64_t i = 0; i < totn; ++i) goff[pnode[i] + 1]++;
@@ -432,7 +424,6 @@ RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_typ
     ps->d_lien = (u8*)CdamMallocDevice((ptrdiff_t)T * 4);
     ps->d_adj = (uint16_t*)CdamMallocDevice((ptrdiff_t)T * 4 * (ptrdiff_t)sizeof(uint16_t));
     ps->d_adj_start = (uint16_t*)CdamMallocDevice(((ptrdiff_t)totn + P) * (ptrdiff_t)sizeof(uint16_t));
-    ps->d_epos = (index_type*)CdamMallocDevice((ptrdiff_t)T * SIZE_OF(index_type));
     ps->d_goff = (index_type*)CdamMallocDevice(((ptrdiff_t)N + 1) * SIZE_OF(index_type));
     ps->d_gidx = (index_type*)CdamMallocDevice((ptrdiff_t)(totn > 0 ? totn : 1) * SIZE_OF(index_type));
     ps->d_partial = (f64*)CdamMallocDevice((ptrdiff_t)(totn > 0 ? totn : 1) * 6 * SIZE_OF(f64));
@@ -442,13 +433,12 @@ RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_typ
     HIPGUARD(hipMemcpy(ps->d_lien, lien, (size_t)T * 4, H2D));
     HIPGUARD(hipMemcpy(ps->d_adj, adj, sizeof(uint16_t) * (size_t)T * 4, H2D));
     HIPGUARD(hipMemcpy(ps->d_adj_start, adj_start, sizeof(uint16_t) * ((size_t)totn + (size_t)P), H2D));
-    HIPGUARD(hipMemcpy(ps->d_epos, ien_p, sizeof(index_type) * (size_t)T, H2D));
     HIPGUARD(hipMemcpy(ps->d_goff, goff, sizeof(index_type) * ((size_t)N + 1), H2D));
     HIPGUARD(hipMemcpy(ps->d_gidx, gidx, sizeof(index_type) * (size_t)totn, H2D));
     if (verbose) fprintf(stderr, "[rhspatch] %d patches, %lld patch nodes (%.2f per node) in %.2f s\n", P, (long long)totn,
                          (double)totn / (double)(N > 0 ? N : 1), omp_get_wtime() - t0);
     for (index_type p = 0; p < P; ++p) free(nodes_of[p]);
-    free(gidx); free(goff); free(ien_p); free(adj_start); free(adj); free(lien); free(pnode);
+    free(gidx); free(goff); free(adj_start); free(adj); free(lien); free(pnode);
     free(nodes_of); free(nn_of); free(noff); free(eoff); free(x.out); free(idx); free(c);
     return ps;
 }
@@ -457,7 +447,7 @@ void DflFreeRhsPatchSchedule(RhsPatchSched* ps) {
     if (!ps) return;
     CdamFreeDevice(ps->d_eoff, 0); CdamFreeDevice(ps->d_noff, 0); CdamFreeDevice(ps->d_pnode, 0);
     CdamFreeDevice(ps->d_lien, 0); CdamFreeDevice(ps->d_adj, 0); CdamFreeDevice(ps->d_adj_start, 0);
-    CdamFreeDevice(ps->d_epos, 0); CdamFreeDevice(ps->d_goff, 0); CdamFreeDevice(ps->d_gidx, 0);
+    CdamFreeDevice(ps->d_goff, 0); CdamFreeDevice(ps->d_gidx, 0);
     CdamFreeDevice(ps->d_partial, 0);
     CdamFreeHost(ps, SIZE_OF(RhsPatchSched));
 }

@@ -221,14 +221,13 @@ void dfl_assemble_tet_rhs(dfl_index batch_size, const dfl_index* ien_b, const df
 /* patch form of the same residual (host/patch.c: DflBuildRhsPatchSchedule): workgroup p evaluates tets
  * [p_eoff[p], p_eoff[p+1]) whose vertices are the patch nodes pnode[p_noff[p] + lien[tet*4 + a]], and writes one
  * 6-component partial record per patch node, partial[(p_noff[p] + k)*6 ..], summed in the order of the adjacency lists
- * (adj / adj_start).  epos[tet] indexes the geometry cache.  dfl_rhs_node_sum then adds, for every node, its partial
+ * (adj / adj_start).  dfl_rhs_node_sum then adds, for every node, its partial
  * records gidx[goff[n] .. goff[n+1]) in that order into F (reference layout).  No atomics: bitwise reproducible. */
 int dfl_rhs_patch_max_nodes(void);
 int dfl_rhs_patch_max_tets(void);
 void dfl_assemble_tet_rhs_patch(dfl_index npatch, const dfl_index* p_eoff, const dfl_index* p_noff, const dfl_index* pnode,
                                  const unsigned char* lien, const unsigned short* adj, const unsigned short* adj_start,
-                                 const dfl_index* epos, const dfl_value* egeo_b, const dfl_value* nodep, dfl_value* partial,
-                                 void* stream);
+                                 const dfl_value* nodep, dfl_value* partial, void* stream);
 void dfl_rhs_node_sum(dfl_index N, const dfl_index* goff, const dfl_index* gidx, const dfl_value* partial, dfl_value* F,
                       void* stream);
 /* patch form of the LHS assembly (assembly schedule 2): one workgroup per spatial patch of tets sums all
