@@ -23,7 +23,13 @@ def _nnz1(M):
     return (M + 1) ** 3 + 2 * E
 
 
-@pytest.mark.parametrize("M", [55, 119])
+import os
+
+# DFL_FULLSIZE_M=203 adds the 50M-tet configuration (BASELINE config 5 size; ~1 min and ~60 GB of HBM) on demand
+_SIZES = [55, 119] + ([int(os.environ["DFL_FULLSIZE_M"])] if os.environ.get("DFL_FULLSIZE_M") else [])
+
+
+@pytest.mark.parametrize("M", _SIZES)
 def test_full_size_properties(api, M):
     m = kuhn_cube(M, jitter=0.2)
     wg, dwg = synthetic_fields(m)
