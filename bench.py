@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--gmres-its", type=int, default=40)
     ap.add_argument("--cpu-M", type=int, default=64, help="cube size of the CPU-baseline sample (0 = skip); 64 = 1.57M tets, ~10-15 s of CPU work")
     ap.add_argument("--jitter", type=float, default=0.2)
+    ap.add_argument("--coupled-M", type=int, default=55, help="fluid mesh of the coupled fluid + DEM step leg (0 = skip)")
     ap.add_argument("--dem-particles", type=int, default=100000, help="DEM contact sweep leg after the timed step (0 = skip)")
     args = ap.parse_args()
 
@@ -258,6 +259,37 @@ def main():
                "particles_per_s": P_ / tw}
         pc.close()
 
+    # ---- coupled step of BASELINE config 4 (1M-tet fluid mesh + 100k DEM particles), outside the timed region ----------
+    coupled = None
+    if args.coupled_M > 0 and args.dem_particles > 0:
+        from dedflow_amd.meshgen import dem_particles
+        m4 = kuhn_cube(args.coupled_M, jitter=args.jitter)
+        w4, dw4 = synthetic_fields(m4)
+        N4 = m4.num_node
+        w4[3 * N4:4 * N4] = 0.0
+        P4 = api.Problem(m4, maxit=120, atol=1e-12, rtol=1e-4, quiet=True)
+        xp, vp_, R = dem_particles(args.dem_particles, 0.004)
+        pc4 = api.Particles(xp, vp_, R, dt=1e-4)
+        st = [api.DeviceArray.from_numpy(a) for a in (w4, 0.1 * dw4, 0.1 * dw4)]
+        F4, dx4 = api.DeviceArray(6 * N4), api.DeviceArray(6 * N4)
+        substeps, newton = 10, 2
+        P4.time_step(st[0], st[1], st[2], F4, dx4, newton_maxit=newton, particles=pc4, dem_substeps=substeps)
+        api.sync()
+        tw = time.perf_counter()
+        nrep = 3
+        its4 = 0
+        for _ in range(nrep):
+            it4, _, _ = P4.time_step(st[0], st[1], st[2], F4, dx4, newton_maxit=newton, particles=pc4, dem_substeps=substeps)
+            its4 += it4
+        api.sync()
+        tw = (time.perf_counter() - tw) / nrep
+        coupled = {"workload": f"Kuhn cube M={args.coupled_M} ({m4.num_tet} tets) + {args.dem_particles} particles: DflTimeStep = predictor, "
+                               f"<= {newton} Newton iterations (F, J assembly + Jacobi-GMRES to rtol 1e-4, <= 120 its), corrector, "
+                               f"{substeps} DEM contact sweeps + particle updates",
+                   "ms_per_coupled_step": 1e3 * tw, "newton_iterations_per_step": its4 / nrep}
+        pc4.close()
+        P4.close()
+
     tJ = kernels.get("asm_lhs", {}).get("total_ms_per_step", 0.0)
     tF = kernels.get("asm_rhs", {}).get("total_ms_per_step", 0.0)
     out = {
@@ -272,7 +304,7 @@ def main():
         "assemble_J_dofs_per_s": (4.0 * N / (tJ * 1e-3)) if tJ else None,
         "assemble_F_dofs_per_s": (6.0 * N / (tF * 1e-3)) if tF else None,
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "dem_sweep": dem,
-        "spmv_back_to_back_ms": spmv_grouped_ms,
+        "spmv_back_to_back_ms": spmv_grouped_ms, "coupled_step": coupled,
         # the whole Krylov solve against the HBM roofline: algorithmic bytes of its `its` matvecs (x0 = 0: r0 = b needs none),
         # its CGS steps, its+1 preconditioner applications and the final basis combination over the un-instrumented solve time
         "krylov_solve": (lambda b: {"ms": solve_ms_timed, "algorithmic_GB": b / 1e9, "GBps": b / (solve_ms_timed * 1e-3) / 1e9,
