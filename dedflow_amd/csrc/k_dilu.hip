@@ -104,33 +104,40 @@ __global__ __launch_bounds__(BLK) void dilu_setup_kernel(I nrows_c, const I* __r
 
 // one color of a triangular sweep.  FWD: z_i = E_i^-1 (r_i - sum_{color(j)<color(i)} A_ij z_j)
 //                                   BWD: z_i -= E_i^-1 sum_{color(j)>color(i)} A_ij z_j
+// The L / U neighbours of every row are precomputed lists (eptr over the color-ordered row slots, enz = nodal nonzero,
+// ecol = column node), so the loop carries no color lookup and no predicate and issues two independent block loads per trip.
 template <bool FWD>
-__global__ __launch_bounds__(BLK) void dilu_sweep_kernel(I nrows_c, const I* __restrict__ rows, I N, I nown,
-                                                        const I* __restrict__ rp, const I* __restrict__ ci,
-                                                        const T* __restrict__ val, const unsigned char* __restrict__ color,
+__global__ __launch_bounds__(BLK) void dilu_sweep_kernel(I slot0, I nrows_c, const I* __restrict__ rows, I N,
+                                                        const I* __restrict__ eptr, const I* __restrict__ enz,
+                                                        const I* __restrict__ ecol, const T* __restrict__ val,
                                                         const T* __restrict__ Einv, const T* __restrict__ r, T* __restrict__ z) {
     const long long gid = (long long)blockIdx.x * BLK + threadIdx.x;
-    const long long slot = gid >> 3;
+    const long long lslot = gid >> 3;
     const int l = threadIdx.x & 7;
-    if (slot >= nrows_c) return;  // whole 8-lane groups leave together
+    if (lslot >= nrows_c) return;  // whole 8-lane groups leave together
+    const long long slot = slot0 + lslot;
     const int row = rows[slot];
-    const int cr = color[row];
     const long long N3 = 3LL * N;
     const int br = l >> 1;
     const bool hi = (l & 1);
     const d2v* __restrict__ v2 = reinterpret_cast<const d2v*>(val) + l;
-    double acc = 0.0;
-    for (int k = rp[row]; k < rp[row + 1]; ++k) {
-        const int c = ci[k];
-        if (c >= nown) continue;  // ghost columns of a partitioned run are left to the Krylov method
-        const int cc = color[c];
-        if (FWD ? (cc < cr) : (cc > cr)) {
-            const d2v a = v2[(long long)k * 8];
-            const long long ia = hi ? 3LL * c + 2 : 3LL * c;
-            const long long ib = hi ? N3 + c : 3LL * c + 1;
-            acc += a.x * z[ia] + a.y * z[ib];
-        }
+    double acc0 = 0.0, acc1 = 0.0;
+    int q = eptr[slot];
+    const int qe = eptr[slot + 1];
+    for (; q + 2 <= qe; q += 2) {
+        const int k0 = enz[q], k1 = enz[q + 1], c0 = ecol[q], c1 = ecol[q + 1];
+        const d2v a0 = v2[(long long)k0 * 8], a1 = v2[(long long)k1 * 8];
+        const double x0a = z[hi ? 3LL * c0 + 2 : 3LL * c0], x0b = z[hi ? N3 + c0 : 3LL * c0 + 1];
+        const double x1a = z[hi ? 3LL * c1 + 2 : 3LL * c1], x1b = z[hi ? N3 + c1 : 3LL * c1 + 1];
+        acc0 += a0.x * x0a + a0.y * x0b;
+        acc1 += a1.x * x1a + a1.y * x1b;
     }
+    if (q < qe) {
+        const int k0 = enz[q], c0 = ecol[q];
+        const d2v a0 = v2[(long long)k0 * 8];
+        acc0 += a0.x * z[hi ? 3LL * c0 + 2 : 3LL * c0] + a0.y * z[hi ? N3 + c0 : 3LL * c0 + 1];
+    }
+    double acc = acc0 + acc1;
     acc += __shfl_xor(acc, 1, WAVE);  // both lanes of block row `br` hold the row sum
     const long long yi = xidx(row, br, N3);
     const double t = FWD ? r[yi] - acc : acc;
@@ -162,12 +169,12 @@ void dfl_dilu_setup_color(I nrows_c, const I* rows, I nown, const I* rp, const I
     DFL_LAUNCH_CHECK();
 }
 
-void dfl_dilu_sweep_color(int forward, I nrows_c, const I* rows, I N, I nown, const I* rp, const I* ci, const T* val,
-                          const unsigned char* color, const T* Einv, const T* r, T* z, void* stream) {
+void dfl_dilu_sweep_color(int forward, I slot0, I nrows_c, const I* rows, I N, const I* eptr, const I* enz, const I* ecol,
+                          const T* val, const T* Einv, const T* r, T* z, void* stream) {
     if (nrows_c <= 0) return;
     const int grid = ceil_div((long long)nrows_c * 8, BLK);
-    if (forward) dilu_sweep_kernel<true><<<grid, BLK, 0, S(stream)>>>(nrows_c, rows, N, nown, rp, ci, val, color, Einv, r, z);
-    else dilu_sweep_kernel<false><<<grid, BLK, 0, S(stream)>>>(nrows_c, rows, N, nown, rp, ci, val, color, Einv, r, z);
+    if (forward) dilu_sweep_kernel<true><<<grid, BLK, 0, S(stream)>>>(slot0, nrows_c, rows, N, eptr, enz, ecol, val, Einv, r, z);
+    else dilu_sweep_kernel<false><<<grid, BLK, 0, S(stream)>>>(slot0, nrows_c, rows, N, eptr, enz, ecol, val, Einv, r, z);
     DFL_LAUNCH_CHECK();
 }
 

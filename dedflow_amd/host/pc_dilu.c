@@ -18,6 +18,8 @@ typedef struct PCDilu {
     index_type* color_offset; /* host [num_color+1] */
     index_type* d_rows;       /* device [nown] rows grouped by color */
     u8* d_color;              /* device [N] */
+    index_type *d_lptr, *d_lnz, *d_lcol; /* device: strictly-lower (by color) neighbours of each row slot */
+    index_type *d_uptr, *d_unz, *d_ucol; /* device: strictly-upper neighbours */
     f64* d_Einv;              /* device [N][16] */
 } PCDilu;
 
@@ -54,6 +56,46 @@ static void dilu_build_colors(PCDilu* d) {
     index_type cur[64];
     memcpy(cur, d->color_offset, sizeof(index_type) * (size_t)nc);
     for (index_type i = 0; i < nown; ++i) rows[cur[color[i]]++] = i;
+    /* per row slot (color order): lists of the lower- and higher-colored neighbours (nonzero index, column) */
+    {
+        index_type* lptr = (index_type*)CdamMallocHost(((ptrdiff_t)nown + 1) * SIZE_OF(index_type));
+        index_type* uptr = (index_type*)CdamMallocHost(((ptrdiff_t)nown + 1) * SIZE_OF(index_type));
+        lptr[0] = uptr[0] = 0;
+        for (index_type sl = 0; sl < nown; ++sl) {
+            const index_type i = rows[sl];
+            index_type nl = 0, nu = 0;
+            for (index_type k = rp[i]; k < rp[i + 1]; ++k) {
+                const index_type j = ci[k];
+                if (j >= nown || j == i) continue;
+                if (color[j] < color[i]) ++nl; else if (color[j] > color[i]) ++nu;
+            }
+            lptr[sl + 1] = lptr[sl] + nl;
+            uptr[sl + 1] = uptr[sl] + nu;
+        }
+        const index_type nL = lptr[nown], nU = uptr[nown];
+        index_type* lnz = (index_type*)CdamMallocHost((ptrdiff_t)(nL > 0 ? nL : 1) * SIZE_OF(index_type));
+        index_type* lcol = (index_type*)CdamMallocHost((ptrdiff_t)(nL > 0 ? nL : 1) * SIZE_OF(index_type));
+        index_type* unz = (index_type*)CdamMallocHost((ptrdiff_t)(nU > 0 ? nU : 1) * SIZE_OF(index_type));
+        index_type* ucol = (index_type*)CdamMallocHost((ptrdiff_t)(nU > 0 ? nU : 1) * SIZE_OF(index_type));
+        for (index_type sl = 0; sl < nown; ++sl) {
+            const index_type i = rows[sl];
+            index_type pl = lptr[sl], pu = uptr[sl];
+            for (index_type k = rp[i]; k < rp[i + 1]; ++k) {
+                const index_type j = ci[k];
+                if (j >= nown || j == i) continue;
+                if (color[j] < color[i]) { lnz[pl] = k; lcol[pl++] = j; }
+                else if (color[j] > color[i]) { unz[pu] = k; ucol[pu++] = j; }
+            }
+        }
+#define UP(dst, src, cnt)                                                                         \
+        dst = (index_type*)CdamMallocDevice((ptrdiff_t)((cnt) > 0 ? (cnt) : 1) * SIZE_OF(index_type)); \
+        HIPGUARD(hipMemcpy(dst, src, sizeof(index_type) * (size_t)(cnt), H2D));
+        UP(d->d_lptr, lptr, nown + 1) UP(d->d_uptr, uptr, nown + 1)
+        UP(d->d_lnz, lnz, nL) UP(d->d_lcol, lcol, nL) UP(d->d_unz, unz, nU) UP(d->d_ucol, ucol, nU)
+#undef UP
+        CdamFreeHost(ucol, 0); CdamFreeHost(unz, 0); CdamFreeHost(lcol, 0); CdamFreeHost(lnz, 0);
+        CdamFreeHost(uptr, 0); CdamFreeHost(lptr, 0);
+    }
     d->d_rows = (index_type*)CdamMallocDevice((ptrdiff_t)(nown > 0 ? nown : 1) * SIZE_OF(index_type));
     d->d_color = (u8*)CdamMallocDevice((ptrdiff_t)(N > 0 ? N : 1));
     HIPGUARD(hipMemcpy(d->d_rows, rows, sizeof(index_type) * (size_t)nown, H2D));
@@ -68,6 +110,9 @@ static void dilu_release_colors(PCDilu* d) {
     if (d->color_offset) CdamFreeHost(d->color_offset, 0);
     CdamFreeDevice(d->d_rows, 0);
     CdamFreeDevice(d->d_color, 0);
+    CdamFreeDevice(d->d_lptr, 0); CdamFreeDevice(d->d_lnz, 0); CdamFreeDevice(d->d_lcol, 0);
+    CdamFreeDevice(d->d_uptr, 0); CdamFreeDevice(d->d_unz, 0); CdamFreeDevice(d->d_ucol, 0);
+    d->d_lptr = d->d_lnz = d->d_lcol = d->d_uptr = d->d_unz = d->d_ucol = NULL;
     d->color_offset = NULL;
     d->d_rows = NULL;
     d->d_color = NULL;
@@ -100,11 +145,11 @@ static void dilu_apply(PC* pc, value_type* x, value_type* y) {
     hipStream_t s = DflStream();
     const index_type n = d->n_active > 0 ? d->n_active : d->n;
     for (index_type c = 0; c < d->num_color; ++c)
-        dfl_dilu_sweep_color(1, d->color_offset[c + 1] - d->color_offset[c], d->d_rows + d->color_offset[c], d->N, d->nown,
-                             d->spy->row_ptr, d->spy->col_ind, val, d->d_color, d->d_Einv, x, y, s);
+        dfl_dilu_sweep_color(1, d->color_offset[c], d->color_offset[c + 1] - d->color_offset[c], d->d_rows, d->N, d->d_lptr, d->d_lnz,
+                             d->d_lcol, val, d->d_Einv, x, y, s);
     for (index_type c = d->num_color - 1; c >= 0; --c)
-        dfl_dilu_sweep_color(0, d->color_offset[c + 1] - d->color_offset[c], d->d_rows + d->color_offset[c], d->N, d->nown,
-                             d->spy->row_ptr, d->spy->col_ind, val, d->d_color, d->d_Einv, x, y, s);
+        dfl_dilu_sweep_color(0, d->color_offset[c], d->color_offset[c + 1] - d->color_offset[c], d->d_rows, d->N, d->d_uptr, d->d_unz,
+                             d->d_ucol, val, d->d_Einv, x, y, s);
     if (d->nown < d->N) { /* ghost entries of a Krylov vector stay zero */
         HIPGUARD(hipMemsetAsync(y + 3 * (size_t)d->nown, 0, sizeof(f64) * 3 * (size_t)(d->N - d->nown), s));
         HIPGUARD(hipMemsetAsync(y + 3 * (size_t)d->N + d->nown, 0, sizeof(f64) * (size_t)(d->N - d->nown), s));

@@ -109,12 +109,14 @@ void dfl_pc_jacobi_apply_rows(dfl_index nrows, dfl_index N, dfl_index n, const d
 void dfl_pc_jacobi_apply_scaled_rows(dfl_index nrows, dfl_index N, dfl_index n, const dfl_value* dinv33, const dfl_value* dinv1,
                                      const dfl_value* w, const dfl_value* d_nrm, dfl_value* q_out, dfl_value* y, void* stream);
 /* multicolor block-DILU (csrc/k_dilu.hip): rows[0:nrows_c] = node rows of one color; color[N] u8; Einv[N][16].
- * setup: E_i^-1 of one color (all lower colors already done); sweep: one color of the forward (z = E^-1(r - L z))
- * or backward (z -= E^-1 U z) substitution; columns >= nown (ghosts) are ignored */
+ * setup: E_i^-1 of one color (all lower colors already done; columns >= nown (ghosts) are ignored).
+ * sweep: one color of the forward (z = E^-1(r - L z)) or backward (z -= E^-1 U z) substitution over rows[slot0 ..
+ * slot0+nrows_c); the strictly lower / upper neighbours of the row at slot s are enz / ecol [eptr[s], eptr[s+1])
+ * (nodal nonzero index and column node), built once per coloring by the host */
 void dfl_dilu_setup_color(dfl_index nrows_c, const dfl_index* rows, dfl_index nown, const dfl_index* row_ptr,
                           const dfl_index* col_ind, const dfl_value* val, const unsigned char* color, dfl_value* Einv, void* stream);
-void dfl_dilu_sweep_color(int forward, dfl_index nrows_c, const dfl_index* rows, dfl_index N, dfl_index nown,
-                          const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val, const unsigned char* color,
+void dfl_dilu_sweep_color(int forward, dfl_index slot0, dfl_index nrows_c, const dfl_index* rows, dfl_index N,
+                          const dfl_index* eptr, const dfl_index* enz, const dfl_index* ecol, const dfl_value* val,
                           const dfl_value* Einv, const dfl_value* r, dfl_value* z, void* stream);
 void dfl_copy_range(int64_t begin, int64_t end, const dfl_value* x, dfl_value* y, void* stream); /* y[begin:end] = x[begin:end] */
 /* scalar CSR SpMV for the reference-layout sub-matrices (cusparseSpMV, matrix.c:151-162) */
