@@ -228,25 +228,57 @@ __device__ void drotg_dev(double* a, double* b, double* c, double* s) {
     *a = r; *b = z;
 }
 
+// The Givens step of column `iter` (krylov.c:256-277, krylov_util.cu:5-19), called by a whole workgroup: the column and
+// the earlier rotations are staged in LDS with coalesced loads first (a single thread walking them in global memory
+// pays one dependent load latency per entry), thread 0 runs the O(iter) recurrence on the staged copy, the column is
+// written back by all threads.  `nrm` = ||w||.
+constexpr int GIV_MAX = 1024;  // columns longer than this fall back to the in-place walk
+__device__ void givens_step_block(I iter, double nrm, T* H, I ldh, T* gv, T* beta, T* res_hist, double* s_col, double* s_gv) {
+    T* col = H + (long long)iter * ldh;
+    const int t = threadIdx.x, nt = blockDim.x;
+    const bool staged = iter + 2 <= GIV_MAX;
+    if (staged) {
+        for (int i = t; i <= iter; i += nt) s_col[i] = col[i];
+        for (int i = t; i < 2 * iter; i += nt) s_gv[i] = gv[i];
+        __syncthreads();
+    }
+    if (t == 0) {
+        double* c_ = staged ? s_col : col;
+        const double* g_ = staged ? s_gv : gv;
+        c_[iter + 1] = nrm;  // H[iter+1, iter] = ||w||, krylov.c:228-230
+        for (I i = 0; i < iter; ++i) {  // cublasDrot(n=1), krylov.c:258-263
+            const double c = g_[2 * i], s = g_[2 * i + 1];
+            const double x = c_[i], y = c_[i + 1];
+            c_[i] = c * x + s * y;
+            c_[i + 1] = c * y - s * x;
+        }
+        double gc, gs;
+        drotg_dev(&c_[iter], &c_[iter + 1], &gc, &gs);  // :266
+        gv[2 * iter] = gc;
+        gv[2 * iter + 1] = gs;
+        c_[iter + 1] = 0.0;  // :267
+        const double b0 = beta[iter];  // krylov_util.cu:5-19
+        beta[iter + 1] = -gs * b0;
+        beta[iter] = b0 * gc;
+        if (res_hist) res_hist[iter] = fabs(beta[iter + 1]);
+    }
+    if (staged) {
+        __syncthreads();
+        for (int i = t; i <= iter + 1; i += nt) col[i] = s_col[i];
+    }
+}
+
 // SQUARED: *d_nrm holds the (all-reduced) squared norm; it is replaced by its square root first
 template <bool SQUARED>
-__global__ void gmres_givens_kernel(I iter, T* d_nrm, T* H, I ldh, T* gv, T* beta, T* res_hist) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (SQUARED) d_nrm[0] = sqrt(d_nrm[0]);
-    T* col = H + (long long)iter * ldh;
-    col[iter + 1] = d_nrm[0];  // H[iter+1, iter] = ||w||, krylov.c:228-230
-    for (I i = 0; i < iter; ++i) {  // cublasDrot(n=1), krylov.c:258-263
-        double c = gv[2 * i], s = gv[2 * i + 1];
-        double x = col[i], y = col[i + 1];
-        col[i] = c * x + s * y;
-        col[i + 1] = c * y - s * x;
+__global__ __launch_bounds__(BLK) void gmres_givens_kernel(I iter, T* d_nrm, T* H, I ldh, T* gv, T* beta, T* res_hist) {
+    __shared__ double s_col[GIV_MAX], s_gv[2 * GIV_MAX];
+    __shared__ double s_nrm;
+    if (threadIdx.x == 0) {
+        s_nrm = SQUARED ? sqrt(d_nrm[0]) : d_nrm[0];
+        if (SQUARED) d_nrm[0] = s_nrm;
     }
-    drotg_dev(&col[iter], &col[iter + 1], &gv[2 * iter], &gv[2 * iter + 1]);  // :266
-    col[iter + 1] = 0.0;                                                     // :267
-    double b0 = beta[iter];                                                  // krylov_util.cu:5-19
-    beta[iter + 1] = -gv[2 * iter + 1] * b0;
-    beta[iter] = b0 * gv[2 * iter];
-    if (res_hist) res_hist[iter] = fabs(beta[iter + 1]);
+    __syncthreads();
+    givens_step_block(iter, s_nrm, H, ldh, gv, beta, res_hist, s_col, s_gv);
 }
 
 // second stage of ||w||^2 (partials of cgs_update_kernel, same fixed order as reduce_stage2) + square root + the Givens
@@ -254,25 +286,17 @@ __global__ void gmres_givens_kernel(I iter, T* d_nrm, T* H, I ldh, T* gv, T* bet
 __global__ __launch_bounds__(BLK) void norm_givens_kernel(int npart, const T* part, T* d_nrm, I iter, T* H, I ldh, T* gv, T* beta,
                                                          T* res_hist) {
     __shared__ double lds[4];
+    __shared__ double s_nrm;
+    __shared__ double s_col[GIV_MAX], s_gv[2 * GIV_MAX];
     double acc = 0.0;
     for (int i = threadIdx.x; i < npart; i += BLK) acc += part[i];
     const double r = block_sum_256(acc, lds);
-    if (threadIdx.x != 0) return;
-    d_nrm[0] = sqrt(r);
-    T* col = H + (long long)iter * ldh;
-    col[iter + 1] = d_nrm[0];
-    for (I i = 0; i < iter; ++i) {
-        double c = gv[2 * i], s = gv[2 * i + 1];
-        double x = col[i], y = col[i + 1];
-        col[i] = c * x + s * y;
-        col[i + 1] = c * y - s * x;
+    if (threadIdx.x == 0) {
+        s_nrm = sqrt(r);
+        d_nrm[0] = s_nrm;
     }
-    drotg_dev(&col[iter], &col[iter + 1], &gv[2 * iter], &gv[2 * iter + 1]);
-    col[iter + 1] = 0.0;
-    double b0 = beta[iter];
-    beta[iter + 1] = -gv[2 * iter + 1] * b0;
-    beta[iter] = b0 * gv[2 * iter];
-    if (res_hist) res_hist[iter] = fabs(beta[iter + 1]);
+    __syncthreads();
+    givens_step_block(iter, s_nrm, H, ldh, gv, beta, res_hist, s_col, s_gv);
 }
 
 __global__ void gmres_trsv_kernel(I m, const T* H, I ldh, T* beta) {
@@ -412,11 +436,11 @@ void dfl_gemv_n(I n, I ncol, const T* Q, int64_t ldq, const T* d_c, T* y, void* 
 }
 
 void dfl_gmres_givens(I iter, const T* d_nrm, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, void* stream) {
-    gmres_givens_kernel<false><<<1, 64, 0, S(stream)>>>(iter, const_cast<T*>(d_nrm), d_H, ldh, d_gv, d_beta, d_res_hist);
+    gmres_givens_kernel<false><<<1, BLK, 0, S(stream)>>>(iter, const_cast<T*>(d_nrm), d_H, ldh, d_gv, d_beta, d_res_hist);
     DFL_LAUNCH_CHECK();
 }
 void dfl_gmres_givens_sq(I iter, T* d_nrm_sq, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, void* stream) {
-    gmres_givens_kernel<true><<<1, 64, 0, S(stream)>>>(iter, d_nrm_sq, d_H, ldh, d_gv, d_beta, d_res_hist);
+    gmres_givens_kernel<true><<<1, BLK, 0, S(stream)>>>(iter, d_nrm_sq, d_H, ldh, d_gv, d_beta, d_res_hist);
     DFL_LAUNCH_CHECK();
 }
 void dfl_gmres_trsv(I m, const T* d_H, I ldh, T* d_beta, void* stream) {
