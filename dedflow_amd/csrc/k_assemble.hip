@@ -921,12 +921,15 @@ __device__ __forceinline__ double quad_bcast(double v) {  // CTRL = 0x00 / 0x55 
     return __hiloint2double(hi, lo);
 }
 
+// PROBE = true only under dfl_tune_asm (developer phase split): the shipped instantiation carries no probe branches
+template <bool PROBE>
 __global__ __launch_bounds__(LBLK, 5) void tet_lhs_rowpatch_kernel(I P, const I* __restrict__ p_ioff, const I* __restrict__ p_soff,
                                                                const I* __restrict__ item_ea,
                                                                const unsigned short* __restrict__ item_slot,
                                                                const I* __restrict__ slot_nz, const I* __restrict__ ien,
                                                                const T* __restrict__ egeo, const T* __restrict__ nodep,
-                                                               T* __restrict__ val, T beta, int dbg) {
+                                                               T* __restrict__ val, T beta, int dbg_in) {
+    const int dbg = PROBE ? dbg_in : 0;
     extern __shared__ double dyn_lds[];
     double* tab = dyn_lds;  // [16][nsp], entry-major
     // XCD-aware order: workgroup w runs on XCD w % 8; give every XCD one contiguous range of the spatially
@@ -1119,12 +1122,17 @@ void dfl_assemble_tet_lhs_rowpatch(I npatch, const I* p_ioff, const I* p_soff, c
     const size_t lds = (size_t)16 * (size_t)(max_slots | 1) * sizeof(double);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_rowpatch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_rowpatch_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_rowpatch_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
     const int grid = 8 * ((npatch + 7) / 8);
-    tet_lhs_rowpatch_kernel<<<grid, LBLK, lds, S(stream)>>>(npatch, p_ioff, p_soff, item_ea, item_slot, slot_nz, ien, egeo,
-                                                            nodep, val, beta, g_patch_dbg);
+    if (g_patch_dbg)
+        tet_lhs_rowpatch_kernel<true><<<grid, LBLK, lds, S(stream)>>>(npatch, p_ioff, p_soff, item_ea, item_slot, slot_nz, ien, egeo,
+                                                                      nodep, val, beta, g_patch_dbg);
+    else
+        tet_lhs_rowpatch_kernel<false><<<grid, LBLK, lds, S(stream)>>>(npatch, p_ioff, p_soff, item_ea, item_slot, slot_nz, ien, egeo,
+                                                                       nodep, val, beta, 0);
     DFL_LAUNCH_CHECK();
 }
 
