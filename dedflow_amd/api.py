@@ -191,7 +191,8 @@ class MatrixFS(C.Structure):
 
 
 class KrylovStats(C.Structure):
-    _fields_ = [("iterations", C.c_int32), ("rnrm_init", C.c_double), ("res_hist", C.c_double * 512), ("converged", C.c_int32)]
+    _fields_ = [("iterations", C.c_int32), ("rnrm_init", C.c_double), ("res_hist", C.c_double * 512), ("converged", C.c_int32),
+                ("fused_norm_cancelled", C.c_int32)]
 
 
 class Dirichlet(C.Structure):
@@ -281,7 +282,7 @@ def _declare(L):
     f("KrylovSetVerbose", None, [vp, i32]); f("KrylovSetComm", None, [vp, C.POINTER(DflComm)])
     f("PCSetup", None, [vp]); f("PCApply", None, [vp, vp, vp]); f("PCDestroy", None, [vp])
     f("PCCreateDILU", vp, [C.POINTER(Matrix)]); f("PCDILUGetColors", i32, [vp, vp]); f("PCDILUGetInverseBlocks", vp, [vp])
-    f("KrylovSetPCType", None, [vp, C.c_int]); f("KrylovGetPC", vp, [vp])
+    f("KrylovSetPCType", None, [vp, C.c_int]); f("KrylovGetPC", vp, [vp]); f("KrylovSetFusedNorm", None, [vp, C.c_int])
     f("AssembleSystemTet", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix)])
     f("AssembleSystemTetFace", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix)])
     f("AssembleSystem", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix), vp, i32])

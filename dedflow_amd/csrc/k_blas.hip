@@ -281,6 +281,31 @@ __global__ __launch_bounds__(BLK) void gmres_givens_kernel(I iter, T* d_nrm, T* 
     givens_step_block(iter, s_nrm, H, ldh, gv, beta, res_hist, s_col, s_gv);
 }
 
+// Partitioned runs, fused-norm option: column `iter` of H holds the all-reduced h_0..h_iter and, in slot iter+1, the
+// all-reduced w.w from the SAME reduction; ||w - Q h||^2 = w.w - sum h_j^2 (Q orthonormal), so the second all-reduce of an
+// Arnoldi step disappears.  Cancellation makes this unsafe when ||w - Qh|| << ||w||: *d_flag is raised when less than
+// 1e-6 of w.w is left (the caller then knows the history is unreliable and can switch the option off).
+__global__ __launch_bounds__(BLK) void gmres_givens_pythagoras_kernel(I iter, T* d_nrm, T* H, I ldh, T* gv, T* beta, T* res_hist,
+                                                                     int* d_flag) {
+    __shared__ double s_col[GIV_MAX], s_gv[2 * GIV_MAX];
+    __shared__ double s_nrm;
+    if (threadIdx.x == 0) {
+        const T* col = H + (long long)iter * ldh;
+        const double ww = col[iter + 1];
+        double hh = 0.0;
+        for (I j = 0; j <= iter; ++j) hh += col[j] * col[j];
+        double r = ww - hh;
+        if (r < 1e-6 * ww) {
+            if (d_flag) *d_flag = 1;
+            if (r < 0.0) r = 0.0;
+        }
+        s_nrm = sqrt(r);
+        d_nrm[0] = s_nrm;
+    }
+    __syncthreads();
+    givens_step_block(iter, s_nrm, H, ldh, gv, beta, res_hist, s_col, s_gv);
+}
+
 // second stage of ||w||^2 (partials of cgs_update_kernel, same fixed order as reduce_stage2) + square root + the Givens
 // step in one launch: one kernel boundary less per Arnoldi step
 __global__ __launch_bounds__(BLK) void norm_givens_kernel(int npart, const T* part, T* d_nrm, I iter, T* H, I ldh, T* gv, T* beta,
@@ -441,6 +466,10 @@ void dfl_gmres_givens(I iter, const T* d_nrm, T* d_H, I ldh, T* d_gv, T* d_beta,
 }
 void dfl_gmres_givens_sq(I iter, T* d_nrm_sq, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, void* stream) {
     gmres_givens_kernel<true><<<1, BLK, 0, S(stream)>>>(iter, d_nrm_sq, d_H, ldh, d_gv, d_beta, d_res_hist);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_gmres_givens_pythagoras(I iter, T* d_nrm, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, int* d_flag, void* stream) {
+    gmres_givens_pythagoras_kernel<<<1, BLK, 0, S(stream)>>>(iter, d_nrm, d_H, ldh, d_gv, d_beta, d_res_hist, d_flag);
     DFL_LAUNCH_CHECK();
 }
 void dfl_gmres_trsv(I m, const T* d_H, I ldh, T* d_beta, void* stream) {

@@ -40,6 +40,8 @@ def setup_rank(mesh, rank, world, device, dist, its, staged):
     if comm is None:
         comm = D.DistSolverComm(plan, alloc, dist)
     comm.install(P.ksp)
+    if os.environ.get("DFL_FUSED_NORM") == "1":  # opt-in: one all-reduce per Arnoldi step (KrylovSetFusedNorm)
+        api.lib().KrylovSetFusedNorm(P.ksp, 1)
     return lm, alloc, P, plan, comm
 
 

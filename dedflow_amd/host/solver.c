@@ -212,6 +212,8 @@ typedef struct KrylovExt {
     DflComm comm;
     b32 has_comm;
     PCType pc_type; /* tree KrylovSolve builds: PC_DECOMPOSITION (reference) or PC_ILU0 */
+    b32 fused_norm; /* partitioned runs: ||w - Qh|| from w.w - sum h^2, one all-reduce per Arnoldi step (off by default) */
+    int* d_flag;    /* device int raised by the fused-norm kernel on heavy cancellation */
     /* cached GMRES work space */
     index_type ws_n, ws_maxit;
     f64 *Q, *H, *tmp, *gv, *beta, *res_hist, *nrm, *work;
@@ -246,6 +248,7 @@ void KrylovSetPCType(Krylov* k, PCType type) {
     kext(k)->pc_type = type;
 }
 PC* KrylovGetPC(const Krylov* k) { return (PC*)k->pc; }
+void KrylovSetFusedNorm(Krylov* k, b32 on) { kext(k)->fused_norm = on; }
 const DflComm* KrylovGetComm(const Krylov* k) { return kext(k)->has_comm ? &kext(k)->comm : NULL; }
 void KrylovSetComm(Krylov* k, const DflComm* comm) {
     KrylovExt* x = kext(k);
@@ -256,6 +259,8 @@ void KrylovSetComm(Krylov* k, const DflComm* comm) {
 static void ws_free(KrylovExt* x) {
     CdamFreeDevice(x->Q, 0); CdamFreeDevice(x->H, 0); CdamFreeDevice(x->tmp, 0); CdamFreeDevice(x->gv, 0);
     CdamFreeDevice(x->beta, 0); CdamFreeDevice(x->res_hist, 0); CdamFreeDevice(x->nrm, 0); CdamFreeDevice(x->work, 0);
+    CdamFreeDevice(x->d_flag, 0);
+    x->d_flag = NULL;
     x->Q = x->H = x->tmp = x->gv = x->beta = x->res_hist = x->nrm = x->work = NULL;
     x->ws_n = x->ws_maxit = 0;
 }
@@ -272,6 +277,7 @@ static void ws_ensure(KrylovExt* x, index_type n, index_type maxit, index_type l
     x->nrm = (f64*)CdamMallocDevice(((ptrdiff_t)maxit + 2) * SIZE_OF(f64));
     x->work_len = dfl_cgs_work_size(n, maxit + 1) + dfl_reduce_work_size();
     x->work = (f64*)CdamMallocDevice((ptrdiff_t)x->work_len * SIZE_OF(f64));
+    x->d_flag = (int*)CdamMallocDevice(16);
     x->ws_n = n;
     x->ws_maxit = maxit;
 }
@@ -384,6 +390,14 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
             DFL_TIMED(DFL_TAG_SPMV, MatrixMatVec(A, tmp, QCOL(iter + 1)));
         }
         /* 3. classical Gram-Schmidt */
+        if (dist && ex->fused_norm) {
+            /* w itself is column iter+1 of Q: one extra "column" of the dots gives w.w, one all-reduce carries h and w.w */
+            DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 2, Q, na, QCOL(iter + 1), HCOL(iter), ex->work, s));
+            ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 2);
+            DFL_TIMED(DFL_TAG_CGS_UPDATE, dfl_cgs_update(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), NULL, 0, ex->work, s));
+            dfl_gmres_givens_pythagoras(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, ex->res_hist, ex->d_flag, s);
+            goto arnoldi_step_done;
+        }
         DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 1, Q, na, QCOL(iter + 1), HCOL(iter), ex->work, s));
         if (dist) ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 1);
         /* 4. Givens rotations + residual recurrence, on the device */
@@ -396,6 +410,7 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
             DFL_TIMED(DFL_TAG_CGS_UPDATE, dfl_cgs_update_givens(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), ex->nrm + iter + 1,
                                                                 ex->work, iter, H, ldh, ex->gv, ex->beta, ex->res_hist, s));
         }
+    arnoldi_step_done:
         if ((iter + 1) % ex->check_interval == 0) {
             HIPGUARD(hipMemcpyAsync(&rnrm, ex->beta + iter + 1, sizeof(f64), D2H, s));
             HIPGUARD(hipStreamSynchronize(s));
@@ -420,6 +435,14 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     }
     index_type nh = iter < 512 ? iter : 512;
     if (nh) HIPGUARD(hipMemcpyAsync(ex->stats.res_hist, ex->res_hist, sizeof(f64) * (size_t)nh, D2H, s));
+    ex->stats.fused_norm_cancelled = FALSE;
+    if (dist && ex->fused_norm) {
+        int flag = 0;
+        HIPGUARD(hipMemcpyAsync(&flag, ex->d_flag, sizeof flag, D2H, s));
+        HIPGUARD(hipStreamSynchronize(s));
+        ex->stats.fused_norm_cancelled = flag != 0;
+        HIPGUARD(hipMemsetAsync(ex->d_flag, 0, sizeof(int), s));
+    }
     HIPGUARD(hipStreamSynchronize(s));
     ex->stats.iterations = iter;
     ex->stats.converged = converged;

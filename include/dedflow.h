@@ -366,6 +366,7 @@ typedef struct KrylovStats {
     f64 rnrm_init;
     f64 res_hist[512]; /* |beta[k+1]| after iteration k */
     b32 converged;
+    b32 fused_norm_cancelled; /* KrylovSetFusedNorm: an iteration kept < 1e-6 of w.w -- history unreliable */
 } KrylovStats;
 const KrylovStats* KrylovGetStats(const Krylov* krylov);
 /* 0: GMRES tests convergence every 20 iterations like the reference (krylov.c:281-290); k>0: every k */
@@ -373,6 +374,10 @@ void KrylovSetCheckInterval(Krylov* krylov, index_type k);
 void KrylovSetVerbose(Krylov* krylov, b32 verbose);
 void KrylovSetPCType(Krylov* krylov, PCType type); /* PC_DECOMPOSITION (default, reference tree) or PC_ILU0 */
 PC* KrylovGetPC(const Krylov* krylov);
+/* partitioned runs only, off by default: the norm of the orthogonalised vector from w.w - sum h_j^2, so that an Arnoldi
+ * step needs ONE all-reduce (h and w.w together) instead of two; rounding differs from the explicit norm and heavy
+ * cancellation raises KrylovStats.fused_norm_cancelled */
+void KrylovSetFusedNorm(Krylov* krylov, b32 on);
 /* optional communicator for element-partitioned runs (one process per GPU); NULL = single GPU */
 typedef struct DflComm {
     void (*allreduce_sum)(void* ctx, f64* d_buf, index_type n); /* in place, device buffer */

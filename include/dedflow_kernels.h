@@ -87,6 +87,11 @@ void dfl_gmres_givens(dfl_index iter, const dfl_value* d_nrm, dfl_value* d_H, df
 /* same, for partitioned runs: *d_nrm_sq holds the all-reduced squared norm and is replaced by its square root first */
 void dfl_gmres_givens_sq(dfl_index iter, dfl_value* d_nrm_sq, dfl_value* d_H, dfl_index ldh, dfl_value* d_gv,
                          dfl_value* d_beta, dfl_value* d_res_hist, void* stream);
+/* fused-norm option of partitioned runs: H[0..iter, iter] = all-reduced h, H[iter+1, iter] = all-reduced w.w from the same
+ * reduction; the norm of the orthogonalised vector comes from w.w - sum h_j^2 (written to *d_nrm); *d_flag (int, may be
+ * NULL) is raised when cancellation leaves less than 1e-6 of w.w */
+void dfl_gmres_givens_pythagoras(dfl_index iter, dfl_value* d_nrm, dfl_value* d_H, dfl_index ldh, dfl_value* d_gv,
+                                 dfl_value* d_beta, dfl_value* d_res_hist, int* d_flag, void* stream);
 /* back substitution H[0:m,0:m] y = beta[0:m] in place on beta (cublasDtrsv, krylov.c:297-301) */
 void dfl_gmres_trsv(dfl_index m, const dfl_value* d_H, dfl_index ldh, dfl_value* d_beta, void* stream);
 void GMRESResidualUpdatePrivate(dfl_value* beta, dfl_value* gv); /* same symbol as krylov_util.cu:22-24 */

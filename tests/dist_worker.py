@@ -139,6 +139,9 @@ def run_gpu(rank, world, M, its):
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     lm, alloc, P, plan, comm = dist_bench.setup_rank(mesh, rank, world, device, dist, its, True)
+    fused = os.environ.get("DFL_FUSED_NORM") == "1"
+    if fused:  # one all-reduce per Arnoldi step (norm from w.w - sum h^2)
+        api.lib().KrylovSetFusedNorm(P.ksp, 1)
     Ng, n, no = mesh.num_node, P.N, lm.n_owned
     wg_t, wg_p = dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(wg, lm, Ng))
     dwg_t, dwg_p = dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(dwg, lm, Ng))
@@ -160,6 +163,10 @@ def run_gpu(rank, world, M, its):
     xl = x_t.cpu().numpy()
     assert np.abs(xl[own4] - xg_[gidx4]).max() <= 1e-6 * np.abs(xg_).max()
     dist.barrier()
+    if fused:
+        st = api.lib().KrylovGetStats(P.ksp).contents
+        assert not st.fused_norm_cancelled
+        assert comm.n_allreduce <= its + 2, comm.n_allreduce   # one per iteration + the initial residual
     if rank == 0:
         print("DIST_GPU_OK", world, comm.n_allreduce, comm.n_halo)
     P.close()

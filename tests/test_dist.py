@@ -19,8 +19,9 @@ def _free_port():
     return p
 
 
-def _launch(mode, world, M, its, timeout=600):
+def _launch(mode, world, M, its, timeout=600, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["OMP_NUM_THREADS"] = "2"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
@@ -58,3 +59,11 @@ def test_rccl_communicator_single_rank_gpu(oracle_lib):
     ranks on one device): bootstrap, in-stream all-reduce, verification against torch.distributed, solve parity."""
     out = _launch("gpu_rccl", 1, 8, 30)
     assert "DIST_RCCL_OK" in out
+
+
+@pytest.mark.gpu
+def test_distributed_fused_norm_option_gpu_gloo(oracle_lib):
+    """KrylovSetFusedNorm: h and w.w in ONE all-reduce per Arnoldi step, ||w - Qh|| from the Pythagorean identity; same
+    residual history as the single-domain oracle within the partitioned-run tolerance, no cancellation flag."""
+    out = _launch("gpu", 2, 8, 30, extra_env={"DFL_FUSED_NORM": "1"})
+    assert "DIST_GPU_OK" in out
