@@ -40,8 +40,6 @@ def setup_rank(mesh, rank, world, device, dist, its, staged):
     if comm is None:
         comm = D.DistSolverComm(plan, alloc, dist)
     comm.install(P.ksp)
-    if os.environ.get("DFL_FUSED_NORM") == "1":  # opt-in: one all-reduce per Arnoldi step (KrylovSetFusedNorm)
-        api.lib().KrylovSetFusedNorm(P.ksp, 1)
     return lm, alloc, P, plan, comm
 
 
@@ -101,8 +99,19 @@ def run(args, rank, world, local_rank):
         x_t.zero_()
         return P.solve(_Ptr(x_p), _Ptr(F_p))
 
+    # one all-reduce per Arnoldi step (h and w.w together, KrylovSetFusedNorm) unless DFL_FUSED_NORM=0; the warm-up steps
+    # double as the check: if any rank saw heavy cancellation in the Pythagorean norm, fall back to the explicit norm
+    fused = os.environ.get("DFL_FUSED_NORM", "1") != "0"
+    L.KrylovSetFusedNorm(P.ksp, 1 if fused else 0)
     for _ in range(args.warmup):
         step()
+        if fused:
+            flag = torch.tensor([float(L.KrylovGetStats(P.ksp).contents.fused_norm_cancelled)], dtype=torch.float64,
+                                device="cpu" if staged else device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() > 0:
+                fused = False
+                L.KrylovSetFusedNorm(P.ksp, 0)
     L.DflProfileEnable(1)
     dist.barrier()
     torch.cuda.synchronize()
@@ -147,7 +156,7 @@ def run(args, rank, world, local_rank):
             "per_rank": {"local_tets": [r[0] for r in per_rank], "owned_nodes": [r[1] for r in per_rank],
                          "halo_send_bytes": [r[2] for r in per_rank], "colors": [r[3] for r in per_rank]},
             "redundant_assembly_fraction": sum(r[0] for r in per_rank) / Tg - 1.0,
-            "communicator": type(comm).__name__,
+            "communicator": type(comm).__name__, "fused_norm_allreduce": bool(fused),
             "collectives_per_step": {"allreduce": comm.n_allreduce // (args.steps + args.warmup),
                                      "halo_exchange": comm.n_halo // (args.steps + args.warmup)},
             "roofline": roofline, "cpu_baseline": None, "setup_s": t_setup,

@@ -160,6 +160,8 @@ def run_gpu(rank, world, M, its):
     assert np.abs(Fl[own4] - Fg[gidx4]).max() <= 1e-10 * np.abs(Fg).max()
     assert it == its and abs(r0 - r0g) <= 1e-12 * r0g
     assert np.abs(hist - histg).max() <= 1e-8 * r0g, np.abs(hist - histg).max() / r0g
+    if rank == 0 and os.environ.get("DFL_PRINT_DEV"):
+        print("HIST_DEV fused=%d max|hist-oracle|/r0 = %.3e" % (fused, np.abs(hist - histg).max() / r0g))
     xl = x_t.cpu().numpy()
     assert np.abs(xl[own4] - xg_[gidx4]).max() <= 1e-6 * np.abs(xg_).max()
     dist.barrier()
