@@ -35,6 +35,7 @@ for r in (0, parts // 2):
         def exchange(self, x): pass
     comm = D.RcclSolverComm(Plan(), dist, device)
     comm.install(P.ksp)
+    L.KrylovSetFusedNorm(P.ksp, 0 if os.environ.get("DFL_FUSED_NORM") == "0" else 1)   # as bench.py --gpus N does
     alloc = D.RawPointerViews(device)
     n, no, Ng = P.N, lm.n_owned, mesh.num_node
     wg_t, wg_p = dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(wg, lm, Ng))
