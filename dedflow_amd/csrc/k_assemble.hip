@@ -701,7 +701,9 @@ __global__ __launch_bounds__(64) void face_kernel(I nf, const I* __restrict__ fa
                                                  const I* __restrict__ forn, const I* __restrict__ ien, I N,
                                                  const T* __restrict__ xg, const T* __restrict__ wg, const T* __restrict__ dwg,
                                                  T* __restrict__ F, const I* __restrict__ rp, const I* __restrict__ ci,
-                                                 T* __restrict__ val) {
+                                                 T* __restrict__ val, T* __restrict__ pF, T* __restrict__ pJ) {
+    // pF / pJ != NULL: two-pass form -- the face's contributions are parked ([i][a][4] and [i][a*4+b][16]) and summed per
+    // node / per nonzero in a fixed order by face_sum_*_kernel: one launch for all faces, no conflict classes
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= nf) return;
     const int f = face_list ? face_list[i] : i;
@@ -798,16 +800,23 @@ __global__ __launch_bounds__(64) void face_kernel(I nf, const I* __restrict__ fa
                 eF[aa][3] -= sb[iq * 4 + aa] * unor * GWB;
             }
         }
+        if (pF) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const long long n = nodes[a];
-            F[3 * n + 0] += eF[a][0];
-            F[3 * n + 1] += eF[a][1];
-            F[3 * n + 2] += eF[a][2];
-            F[3LL * N + n] += eF[a][3];
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pF[(long long)i * 16 + a * 4 + j] = eF[a][j];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const long long n = nodes[a];
+                F[3 * n + 0] += eF[a][0];
+                F[3 * n + 1] += eF[a][1];
+                F[3 * n + 2] += eF[a][2];
+                F[3LL * N + n] += eF[a][3];
+            }
         }
     }
-    if (val) {
+    if (val || pJ) {
         const double fact2 = kDT * kALPHAF * kGAMMA;
         double shnorm[4];
 #pragma unroll
@@ -852,12 +861,43 @@ __global__ __launch_bounds__(64) void face_kernel(I nf, const I* __restrict__ fa
                         Bk[ii * 4 + 3] += ss * nv[ii] * GWB;       // dRM/dP
                     }
                 }
-                const int nz = find_nz(rp, ci, nodes[aa], nodes[bb]);
-                T* dst = val + (long long)nz * 16;
+                if (pJ) {
+                    T* dst = pJ + ((long long)i * 16 + aa * 4 + bb) * 16;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) dst[k] += Bk[k];
+                    for (int k = 0; k < 16; ++k) dst[k] = Bk[k];
+                } else {
+                    const int nz = find_nz(rp, ci, nodes[aa], nodes[bb]);
+                    T* dst = val + (long long)nz * 16;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) dst[k] += Bk[k];
+                }
             }
     }
+}
+
+// second pass of the face assembly: F[node] += parked contributions of the faces around it, ascending face order
+__global__ __launch_bounds__(256) void face_sum_F_kernel(I nn, const I* __restrict__ fnode, const I* __restrict__ off,
+                                                        const I* __restrict__ ent, const T* __restrict__ pF, I N,
+                                                        T* __restrict__ F) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long k = t >> 2;
+    const int j = (int)(t & 3);
+    if (k >= nn) return;
+    double s = 0.0;
+    for (I q = off[k]; q < off[k + 1]; ++q) s += pF[(long long)ent[q] * 4 + j];
+    const long long n = fnode[k];
+    F[j < 3 ? 3 * n + j : 3LL * N + n] += s;
+}
+// ... and val[nz] += parked blocks, 16 lanes per nonzero
+__global__ __launch_bounds__(256) void face_sum_J_kernel(I nz_count, const I* __restrict__ fnz, const I* __restrict__ off,
+                                                        const I* __restrict__ ent, const T* __restrict__ pJ, T* __restrict__ val) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long k = t >> 4;
+    const int c = (int)(t & 15);
+    if (k >= nz_count) return;
+    double s = 0.0;
+    for (I q = off[k]; q < off[k + 1]; ++q) s += pJ[(long long)ent[q] * 16 + c];
+    val[(long long)fnz[k] * 16 + c] += s;
 }
 
 // per-element geometry cache for the LHS kernels: shg[12], detJ, gg = sum G_ij^2, 1/trace(G), pad
@@ -1175,7 +1215,27 @@ void dfl_unpack_rhs(I N, T* Fp, T* F, void* stream) {
 void dfl_assemble_face(I nf, const I* face_list, const I* f2e, const I* forn, const I* ien, I N, const T* xg, const T* wg,
                        const T* dwg, T* F, const I* rp, const I* ci, T* val, void* stream) {
     if (nf <= 0) return;
-    face_kernel<<<ceil_div(nf, 64), 64, 0, S(stream)>>>(nf, face_list, f2e, forn, ien, N, xg, wg, dwg, F, rp, ci, val);
+    face_kernel<<<ceil_div(nf, 64), 64, 0, S(stream)>>>(nf, face_list, f2e, forn, ien, N, xg, wg, dwg, F, rp, ci, val, nullptr,
+                                                         nullptr);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_assemble_face_park(I nf, const I* f2e, const I* forn, const I* ien, I N, const T* xg, const T* wg, const T* dwg,
+                            T* pF, T* pJ, void* stream) {
+    if (nf <= 0) return;
+    // F / val are only used as "is this part wanted" switches inside the kernel
+    face_kernel<<<ceil_div(nf, 64), 64, 0, S(stream)>>>(nf, nullptr, f2e, forn, ien, N, xg, wg, dwg, pF, nullptr, nullptr, nullptr, pF,
+                                                         pJ);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_face_sum_F(I nn, const I* fnode, const I* off, const I* ent, const T* pF, I N, T* F, void* stream) {
+    if (nn <= 0) return;
+    face_sum_F_kernel<<<ceil_div((long long)nn * 4, 256), 256, 0, S(stream)>>>(nn, fnode, off, ent, pF, N, F);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_face_sum_J(I nz_count, const I* fnz, const I* off, const I* ent, const T* pJ, T* val, void* stream) {
+    if (nz_count <= 0) return;
+    face_sum_J_kernel<<<ceil_div((long long)nz_count * 16, 256), 256, 0, S(stream)>>>(nz_count, fnz, off, ent, pJ, val);
     DFL_LAUNCH_CHECK();
 }
 

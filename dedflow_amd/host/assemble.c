@@ -158,12 +158,12 @@ void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, 
     const index_type* f2e = Mesh3DBoundF2E(mesh, group);
     const index_type* forn = Mesh3DBoundFORN(mesh, group);
     int slot = DflProfileBegin(DFL_TAG_FACE);
-    for (index_type c = 0; c < x->face_num_class; ++c) { /* one launch per conflict-free face class */
-        index_type lo = x->face_color_offset[c], nf = x->face_color_offset[c + 1] - lo;
-        if (!nf) continue;
-        dfl_assemble_face(nf, x->face_list + lo, f2e, forn, dev->ien, N, dev->xg, wgalpha_dptr, dwgalpha_dptr, F,
-                          spy ? spy->row_ptr : NULL, spy ? spy->col_ind : NULL, val, s);
-    }
+    if (spy) DflMeshPrepareFaceNonzeros(mesh, group, spy);
+    /* pass 1: every face parks its terms; pass 2: ordered sums into F and the block values */
+    dfl_assemble_face_park(x->face_nf, f2e, forn, dev->ien, N, dev->xg, wgalpha_dptr, dwgalpha_dptr, F ? x->face_pF : NULL,
+                           spy ? x->face_pJ : NULL, s);
+    if (F) dfl_face_sum_F(x->face_nn, x->face_node, x->face_node_off, x->face_node_ent, x->face_pF, N, F, s);
+    if (spy) dfl_face_sum_J(x->face_nnz, x->face_nz, x->face_nz_off, x->face_nz_ent, x->face_pJ, val, s);
     DflProfileEnd(slot);
 }
 

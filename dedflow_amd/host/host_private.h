@@ -56,10 +56,14 @@ typedef struct MeshExt {
     index_type* sched_offset;      /* host [sched_num+1] */
     index_type* nzmap_b;           /* device [T][16], (elem,a,b) -> nodal nonzero, batch order */
     const CSRAttr* nzmap_attr;     /* pattern the map was built for */
-    index_type face_group;         /* boundary group the face list below belongs to (-1: none) */
-    index_type* face_list;         /* device: faces of that group ordered by class */
-    index_type* face_color_offset; /* host [face_num_class+1] */
-    index_type face_num_class;     /* conflict-free face classes (greedy node coloring of the group's faces) */
+    index_type face_group;         /* boundary group the face lists below belong to (-1: none) */
+    index_type face_nf;            /* faces of that group */
+    index_type face_nn;            /* nodes touched by their parent tets */
+    index_type *face_node, *face_node_off, *face_node_ent; /* device: node, CSR offsets, entries f*4+a (ascending f) */
+    const CSRAttr* face_attr;      /* pattern the nonzero lists below were built for */
+    index_type face_nnz;           /* nodal nonzeros touched by the faces' 4x4 node blocks */
+    index_type *face_nz, *face_nz_off, *face_nz_ent;       /* device: nonzero, CSR offsets, entries f*16+a*4+b */
+    f64 *face_pF, *face_pJ;        /* device parking buffers [nf][16] and [nf][256] */
     index_type* h_f2e;             /* host copy of bound_f2e */
     index_type* h_sched_elem;      /* host [T]: element id at each position of the execution schedule */
     f64* egeo_b;                   /* device [T][16] element geometry cache in schedule order (LHS kernel) */
@@ -71,6 +75,8 @@ typedef struct MeshExt {
 } MeshExt;
 
 void DflMeshPrepareFaces(Mesh3D* mesh, index_type group);
+void DflMeshPrepareFaceNonzeros(Mesh3D* mesh, index_type group, const CSRAttr* spy);
+void DflMeshFreeFaceLists(struct MeshExt* x);
 int DflAssemblyScheduleMode(void);
 /* AssembleSystemTet with J = beta_J * J + contributions (beta_J = 0 only takes effect in schedule 3) */
 void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, f64 beta_J);

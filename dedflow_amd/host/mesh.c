@@ -98,8 +98,7 @@ void Mesh3DDestroy(Mesh3D* m) {
         if (x->h_sched_elem) CdamFreeHost(x->h_sched_elem, 0);
         CdamFreeDevice(x->nodep, 0);
         CdamFreeDevice(x->Fp, 0);
-        CdamFreeDevice(x->face_list, 0);
-        if (x->face_color_offset) CdamFreeHost(x->face_color_offset, 0);
+        DflMeshFreeFaceLists(x);
         if (x->sched_offset) CdamFreeHost(x->sched_offset, 0);
         if (x->h_f2e) CdamFreeHost(x->h_f2e, 0);
         CdamFreeHost(x, SIZE_OF(MeshExt));
@@ -253,48 +252,102 @@ void Mesh3DGenerateColorBatch(Mesh3D* mesh) {
 
 /* faces of one boundary group ordered by the color of their parent tet
  * (replaces the per-color SetupMaskKernel passes, src/assemble.cu:1916-1945) */
+static int cmp_pair(const void* a, const void* b) {
+    const int64_t x = *(const int64_t*)a, y = *(const int64_t*)b;
+    return (x > y) - (x < y);
+}
+/* key-sorted (key, entry) pairs -> distinct keys, CSR offsets, entries; uploaded */
+static index_type upload_groups(int64_t* pairs, index_type n, index_type** d_key, index_type** d_off, index_type** d_ent) {
+    qsort(pairs, (size_t)n, sizeof(int64_t), cmp_pair); /* key in the high word, entry in the low word: entries ascend */
+    index_type* key = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (ptrdiff_t)(n > 0 ? n : 1));
+    index_type* off = (index_type*)CdamMallocHost(SIZE_OF(index_type) * ((ptrdiff_t)n + 1));
+    index_type* ent = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (ptrdiff_t)(n > 0 ? n : 1));
+    index_type nk = 0;
+    for (index_type i = 0; i < n; ++i) {
+        const index_type k = (index_type)(pairs[i] >> 32);
+        if (i == 0 || k != key[nk - 1]) { key[nk] = k; off[nk] = i; ++nk; }
+        ent[i] = (index_type)(pairs[i] & 0xffffffffLL);
+    }
+    off[nk] = n;
+    *d_key = (index_type*)CdamMallocDevice(SIZE_OF(index_type) * (ptrdiff_t)(nk > 0 ? nk : 1));
+    *d_off = (index_type*)CdamMallocDevice(SIZE_OF(index_type) * ((ptrdiff_t)nk + 1));
+    *d_ent = (index_type*)CdamMallocDevice(SIZE_OF(index_type) * (ptrdiff_t)(n > 0 ? n : 1));
+    HIPGUARD(hipMemcpy(*d_key, key, sizeof(index_type) * (size_t)nk, H2D));
+    HIPGUARD(hipMemcpy(*d_off, off, sizeof(index_type) * ((size_t)nk + 1), H2D));
+    HIPGUARD(hipMemcpy(*d_ent, ent, sizeof(index_type) * (size_t)n, H2D));
+    CdamFreeHost(ent, 0); CdamFreeHost(off, 0); CdamFreeHost(key, 0);
+    return nk;
+}
+
+static void face_free_nz_lists(MeshExt* x) {
+    CdamFreeDevice(x->face_nz, 0); CdamFreeDevice(x->face_nz_off, 0); CdamFreeDevice(x->face_nz_ent, 0);
+    CdamFreeDevice(x->face_pJ, 0);
+    x->face_nz = x->face_nz_off = x->face_nz_ent = NULL;
+    x->face_pJ = NULL;
+    x->face_attr = NULL;
+    x->face_nnz = 0;
+}
+void DflMeshFreeFaceLists(MeshExt* x) {
+    face_free_nz_lists(x);
+    CdamFreeDevice(x->face_node, 0); CdamFreeDevice(x->face_node_off, 0); CdamFreeDevice(x->face_node_ent, 0);
+    CdamFreeDevice(x->face_pF, 0);
+    x->face_node = x->face_node_off = x->face_node_ent = NULL;
+    x->face_pF = NULL;
+    x->face_group = -1;
+}
+
+/* Weak-BC faces of one boundary group (the reference scatters them once per ELEMENT color: 141 masked passes at 10M
+ * tets for 28k faces).  Here ONE launch parks every face's contributions and a second sums them per node / per nodal
+ * nonzero in ascending face order -- deterministic, no conflict classes.  This builds the node lists. */
 void DflMeshPrepareFaces(Mesh3D* mesh, index_type group) {
     MeshExt* x = (MeshExt*)mesh->ext;
     if (x->face_group == group) return;
-    /* The reference scatters the faces once per ELEMENT color (141 masked passes at 10M tets for
-     * 28k faces).  Faces only conflict through the 4 nodes of their parent tets, so they are
-     * greedily colored here into a handful of conflict-free classes (<= 64) -> one launch per class.
-     * Deterministic; the order in which a node receives its face contributions is class order
-     * instead of parent-color order (rounding-level difference only). */
-    index_type nf = Mesh3DBoundNumElem(mesh, group), N = mesh->num_node;
-    index_type lo = mesh->bound_elem_offset[group];
+    DflMeshFreeFaceLists(x);
+    const index_type nf = Mesh3DBoundNumElem(mesh, group);
+    const index_type lo = mesh->bound_elem_offset[group];
     const index_type* h_ien = mesh->host->ien;
-    CdamFreeDevice(x->face_list, 0);
-    if (x->face_color_offset) CdamFreeHost(x->face_color_offset, 0);
-    x->face_color_offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * 66);
-    memset(x->face_color_offset, 0, sizeof(index_type) * 66);
-    u64* node_mask = (u64*)CdamMallocHost((ptrdiff_t)N * (ptrdiff_t)sizeof(u64));
-    memset(node_mask, 0, (size_t)N * sizeof(u64));
-    u8* cls = (u8*)CdamMallocHost((ptrdiff_t)(nf > 0 ? nf : 1));
-    index_type ncls = 0;
+    int64_t* pairs = (int64_t*)CdamMallocHost((ptrdiff_t)(nf > 0 ? nf : 1) * 4 * (ptrdiff_t)sizeof(int64_t));
     for (index_type f = 0; f < nf; ++f) {
         const index_type* nd = h_ien + (size_t)x->h_f2e[lo + f] * 4;
-        u64 used = node_mask[nd[0]] | node_mask[nd[1]] | node_mask[nd[2]] | node_mask[nd[3]];
-        int c = 0;
-        while (c < 63 && ((used >> c) & 1ULL)) ++c;
-        ASSERT(!((used >> c) & 1ULL) && "more than 64 face classes");
-        cls[f] = (u8)c;
-        for (int a = 0; a < 4; ++a) node_mask[nd[a]] |= (1ULL << c);
-        if (c + 1 > ncls) ncls = c + 1;
-        x->face_color_offset[c + 1]++;
+        for (int a = 0; a < 4; ++a) pairs[(size_t)f * 4 + a] = ((int64_t)nd[a] << 32) | (int64_t)(f * 4 + a);
     }
-    for (index_type c = 0; c < ncls; ++c) x->face_color_offset[c + 1] += x->face_color_offset[c];
-    index_type* list = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (ptrdiff_t)(nf > 0 ? nf : 1));
-    index_type cur[65];
-    memcpy(cur, x->face_color_offset, sizeof(index_type) * 65);
-    for (index_type f = 0; f < nf; ++f) list[cur[cls[f]]++] = f; /* stable: ascending face id per class */
-    x->face_list = (index_type*)CdamMallocDevice(SIZE_OF(index_type) * (ptrdiff_t)(nf > 0 ? nf : 1));
-    HIPGUARD(hipMemcpy(x->face_list, list, sizeof(index_type) * (size_t)nf, H2D));
+    x->face_nn = upload_groups(pairs, nf * 4, &x->face_node, &x->face_node_off, &x->face_node_ent);
+    CdamFreeHost(pairs, 0);
+    x->face_pF = (f64*)CdamMallocDevice((ptrdiff_t)(nf > 0 ? nf : 1) * 16 * SIZE_OF(f64));
+    x->face_nf = nf;
     x->face_group = group;
-    x->face_num_class = ncls;
-    CdamFreeHost(list, 0);
-    CdamFreeHost(cls, 0);
-    CdamFreeHost(node_mask, 0);
+}
+
+/* nonzero lists of the same faces for a given nodal pattern (built when a Jacobian is first assembled with it) */
+void DflMeshPrepareFaceNonzeros(Mesh3D* mesh, index_type group, const CSRAttr* spy) {
+    MeshExt* x = (MeshExt*)mesh->ext;
+    DflMeshPrepareFaces(mesh, group);
+    if (x->face_attr == spy && x->face_nz) return;
+    face_free_nz_lists(x);
+    const index_type nf = x->face_nf, N = mesh->num_node;
+    const index_type lo = mesh->bound_elem_offset[group];
+    const index_type* h_ien = mesh->host->ien;
+    index_type* rp = (index_type*)CdamMallocHost(((ptrdiff_t)N + 1) * SIZE_OF(index_type));
+    index_type* ci = (index_type*)CdamMallocHost((ptrdiff_t)spy->nnz * SIZE_OF(index_type));
+    HIPGUARD(hipMemcpy(rp, spy->row_ptr, sizeof(index_type) * ((size_t)N + 1), D2H));
+    HIPGUARD(hipMemcpy(ci, spy->col_ind, sizeof(index_type) * (size_t)spy->nnz, D2H));
+    int64_t* pairs = (int64_t*)CdamMallocHost((ptrdiff_t)(nf > 0 ? nf : 1) * 16 * (ptrdiff_t)sizeof(int64_t));
+    for (index_type f = 0; f < nf; ++f) {
+        const index_type* nd = h_ien + (size_t)x->h_f2e[lo + f] * 4;
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                index_type l = rp[nd[a]], h = rp[nd[a] + 1] - 1; /* ascending col_ind: binary search */
+                while (l < h) {
+                    index_type mid = (l + h) >> 1;
+                    if (ci[mid] < nd[b]) l = mid + 1; else h = mid;
+                }
+                pairs[(size_t)f * 16 + a * 4 + b] = ((int64_t)l << 32) | (int64_t)(f * 16 + a * 4 + b);
+            }
+    }
+    x->face_nnz = upload_groups(pairs, nf * 16, &x->face_nz, &x->face_nz_off, &x->face_nz_ent);
+    CdamFreeHost(pairs, 0); CdamFreeHost(ci, 0); CdamFreeHost(rp, 0);
+    x->face_pJ = (f64*)CdamMallocDevice((ptrdiff_t)(nf > 0 ? nf : 1) * 256 * SIZE_OF(f64));
+    x->face_attr = spy;
 }
 
 /* ---- csr.h ------------------------------------------------------------------------ */

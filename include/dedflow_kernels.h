@@ -261,6 +261,16 @@ void dfl_assemble_face(dfl_index n_face, const dfl_index* face_list, const dfl_i
                        const dfl_index* ien, dfl_index N, const dfl_value* xg, const dfl_value* wgalpha,
                        const dfl_value* dwgalpha, dfl_value* F /*or NULL*/, const dfl_index* row_ptr, const dfl_index* col_ind,
                        dfl_value* val /*or NULL*/, void* stream);
+/* two-pass form of the same face terms: every face parks its contributions (pF[f][a][4], pJ[f][a*4+b][16]; NULL = part not
+ * wanted), then each touched node / nodal nonzero sums its entries ent[off[k] .. off[k+1]) (= f*4+a resp. f*16+a*4+b) in
+ * that order.  One launch for all faces instead of one per conflict-free class; summation order fixed by the lists. */
+void dfl_assemble_face_park(dfl_index nf, const dfl_index* f2e, const dfl_index* forn, const dfl_index* ien, dfl_index N,
+                            const dfl_value* xg, const dfl_value* wg, const dfl_value* dwg, dfl_value* pF, dfl_value* pJ,
+                            void* stream);
+void dfl_face_sum_F(dfl_index num_node_entries, const dfl_index* fnode, const dfl_index* off, const dfl_index* ent,
+                    const dfl_value* pF, dfl_index N, dfl_value* F, void* stream);
+void dfl_face_sum_J(dfl_index num_nz_entries, const dfl_index* fnz, const dfl_index* off, const dfl_index* ent,
+                    const dfl_value* pJ, dfl_value* val, void* stream);
 
 /* ---- DEM contact sweep (build-defined; the reference's Particle.c holds storage only)
  *  model: monodisperse spheres, linear spring-dashpot normal contact F = (kn*overlap - gamma_n*vn) n between
