@@ -226,6 +226,36 @@ struct EqFlag {
     __device__ bool operator()(I i) const { return data[i] == value; }
 };
 
+__device__ __forceinline__ I csr_find(const I* __restrict__ ci, I lo, I hi, I col) {  // ascending ci in [lo, hi)
+    I l = lo, h = hi - 1;
+    if (l > h) return -1;
+    while (l < h) {
+        const I mid = (l + h) >> 1;
+        if (ci[mid] < col) l = mid + 1; else h = mid;
+    }
+    return ci[l] == col ? l : -1;
+}
+__global__ void find_nz_batched_kernel(I n, const I* __restrict__ rp, const I* __restrict__ ci, const I* __restrict__ row,
+                                       const I* __restrict__ col, I* __restrict__ ind) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i < n) ind[i] = csr_find(ci, rp[row[i]], rp[row[i] + 1], col[i]);
+}
+__global__ void set_values_coo_kernel(double* __restrict__ matval, double alpha, const I* __restrict__ rp, const I* __restrict__ ci,
+                                      I n, const I* __restrict__ row, const I* __restrict__ col, const double* __restrict__ val,
+                                      double beta) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    const I k = csr_find(ci, rp[row[i]], rp[row[i] + 1], col[i]);
+    if (k >= 0) matval[k] = alpha * matval[k] + beta * val[i];
+}
+__global__ void set_values_ind_kernel(double* __restrict__ matval, double alpha, I n, const I* __restrict__ ind,
+                                      const double* __restrict__ val, double beta) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    const I k = ind ? ind[i] : (I)i;
+    matval[k] = alpha * matval[k] + beta * val[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -345,6 +375,15 @@ void FindValueColor(const I* data, I n, I value, I* result) {
     DFL_GUARD(hipFree(d_count));
 }
 
+// index_type flavours of the same two launchers (indexing.h:9-10) and the buffer-taking count (indexing.h:13; the buffer
+// of the reference's cub path is not needed)
+I CountValueI(const I* data, I n, I value) { return CountValueColorLegacy(data, n, value); }
+void FindValueI(const I* data, I n, I value, I* result) { FindValueColor(data, n, value, result); }
+I CountValueColor(const I* data, I n, I value, void* buffer) {
+    (void)buffer;
+    return CountValueColorLegacy(data, n, value);
+}
+
 void dfl_color_batches(const I* color, I T_, I num_color, I* h_batch_offset, I* batch_ind) {
     // counts
     I* d_hist = nullptr;
@@ -399,6 +438,30 @@ void dfl_pattern_fill(I N, const I* ien, const I* rp, const I* ci, const I* row_
 
 void dfl_csr_expand(I N, const I* rp, const I* ci, I br, I bc, I* nrp, I* nci, void* stream) {
     expand_kernel<<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, rp, ci, br, bc, nrp, nci);
+    DFL_LAUNCH_CHECK();
+}
+
+// ind[i] = position of (row[i], col[i]) in the pattern, -1 if absent (csr_impl.h:7-9).  The reference kernel compares
+// col[j] with col[i] instead of col_ind[j] (csr_impl.cu:102) and leaves ind[i] untouched when nothing matches; this is
+// the evident intent.
+void dfl_csr_find_nz(I batch_size, const I* rp, const I* ci, const I* row, const I* col, I* ind, void* stream) {
+    if (batch_size <= 0) return;
+    find_nz_batched_kernel<<<ceil_div(batch_size, BLK), BLK, 0, S(stream)>>>(batch_size, rp, ci, row, col, ind);
+    DFL_LAUNCH_CHECK();
+}
+// matval[k(row[i], col[i])] = alpha * matval[k] + beta * val[i]  (matrix_impl.cu:58-69)
+void MatrixCSRSetValuesCOOGPU(double* matval, double alpha, I num_row, I num_col, const I* rp, const I* ci, I n, const I* row,
+                              const I* col, const double* val, double beta) {
+    (void)num_row; (void)num_col;
+    if (n <= 0) return;
+    set_values_coo_kernel<<<ceil_div(n, BLK), BLK>>>(matval, alpha, rp, ci, n, row, col, val, beta);
+    DFL_LAUNCH_CHECK();
+}
+// matval[ind[i]] = alpha * matval[ind[i]] + beta * val[i].  The reference kernel ignores `ind` and updates matval[i]
+// (matrix_impl.cu:84); an identity `ind` gives the same result here.
+void MatrixCSRSetValuesIndGPU(double* matval, double alpha, I n, const I* ind, const double* val, double beta) {
+    if (n <= 0) return;
+    set_values_ind_kernel<<<ceil_div(n, BLK), BLK>>>(matval, alpha, n, ind, val, beta);
     DFL_LAUNCH_CHECK();
 }
 

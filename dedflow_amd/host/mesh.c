@@ -351,6 +351,12 @@ void DflMeshPrepareFaceNonzeros(Mesh3D* mesh, index_type group, const CSRAttr* s
 }
 
 /* ---- csr.h ------------------------------------------------------------------------ */
+/* csr_impl.h:7-9 */
+void CSRAttrGetNZIndBatchedGPU(const CSRAttr* attr, csr_index_type batch_size, const index_type* row, const index_type* col,
+                               csr_index_type* ind) {
+    dfl_csr_find_nz(batch_size, attr->row_ptr, attr->col_ind, row, col, ind, DflStream());
+}
+
 CSRAttr* CSRAttrCreate(const Mesh3D* mesh) {
     CSRAttr* attr = (CSRAttr*)CdamMallocHost(SIZE_OF(CSRAttr));
     memset(attr, 0, sizeof *attr);
@@ -407,6 +413,12 @@ CSRAttr* CSRAttrCreateBlock(const CSRAttr* attr, csr_index_type br, csr_index_ty
         HIPGUARD(hipStreamSynchronize(DflStream()));
     }
     return na;
+}
+
+/* ExpandCSRByBlockSize, csr_impl.cu:126-156: fills the (already allocated) expanded pattern; last row_ptr entry written (Q3) */
+void ExpandCSRByBlockSize(const CSRAttr* attr, CSRAttr* new_attr, csr_index_type block_size[2]) {
+    dfl_csr_expand(attr->num_row, attr->row_ptr, attr->col_ind, block_size[0], block_size[1], new_attr->row_ptr, new_attr->col_ind,
+                   DflStream());
 }
 
 void CSRAttrDestroy(CSRAttr* attr) {

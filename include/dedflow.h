@@ -194,6 +194,10 @@ struct CSRAttr {
 CSRAttr* CSRAttrCreate(const Mesh3D* mesh);
 void CSRAttrDestroy(CSRAttr* attr);
 CSRAttr* CSRAttrCreateBlock(const CSRAttr* attr, csr_index_type block_row, csr_index_type block_col);
+/* csr_impl.h:6-9 */
+void ExpandCSRByBlockSize(const CSRAttr* attr, CSRAttr* new_attr, csr_index_type block_size[2]);
+void CSRAttrGetNZIndBatchedGPU(const CSRAttr* attr, csr_index_type batch_size, const index_type* row, const index_type* col,
+                               csr_index_type* ind);
 
 /* ---- matrices (matrix.h) --------------------------------------------------------- */
 typedef enum MatType { MAT_TYPE_NONE = 0, MAT_TYPE_DENSE = 1, MAT_TYPE_CSR = 2, MAT_TYPE_FS = 4, MAT_TYPE_CUSTOM = 8 } MatType;

@@ -199,6 +199,18 @@ void ColorElementJPLTetGPU(const dfl_index* ien, const dfl_index* row_ptr, const
 void GetMaxColorGPU(const dfl_index* color, dfl_index num_elem, dfl_index* h_max_color);
 dfl_index CountValueColorLegacy(const dfl_index* data, dfl_index n, dfl_index value);
 void FindValueColor(const dfl_index* data, dfl_index n, dfl_index value, dfl_index* result);
+dfl_index CountValueI(const dfl_index* data, dfl_index n, dfl_index value);                      /* indexing.h:9 */
+void FindValueI(const dfl_index* data, dfl_index n, dfl_index value, dfl_index* result);          /* indexing.h:10 */
+dfl_index CountValueColor(const dfl_index* data, dfl_index n, dfl_index value, void* buffer);     /* indexing.h:13, buffer unused */
+/* positions of (row[i], col[i]) in a CSR pattern, -1 if absent (kernel behind CSRAttrGetNZIndBatchedGPU, csr_impl.h:7-9) */
+void dfl_csr_find_nz(dfl_index batch_size, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_index* row,
+                     const dfl_index* col, dfl_index* ind, void* stream);
+/* matrix_impl.h:17-26 (scalar CSR value setters; off the hot path, kept for launcher-level completeness) */
+void MatrixCSRSetValuesCOOGPU(dfl_value* matval, dfl_value alpha, dfl_index num_row, dfl_index num_col, const dfl_index* row_ptr,
+                              const dfl_index* col_ind, dfl_index n, const dfl_index* row, const dfl_index* col,
+                              const dfl_value* val, dfl_value beta);
+void MatrixCSRSetValuesIndGPU(dfl_value* matval, dfl_value alpha, dfl_index n, const dfl_index* ind, const dfl_value* val,
+                              dfl_value beta);
 /* all colors at once: stable counting sort of element ids by color.
  * h_batch_offset[num_color+1] (host), batch_ind[T] (device). Synchronises. */
 void dfl_color_batches(const dfl_index* color, dfl_index T, dfl_index num_color, dfl_index* h_batch_offset,

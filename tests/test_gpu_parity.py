@@ -421,6 +421,64 @@ def test_krylov_zero_rhs_returns_immediately(api):
         P.close()
 
 
+def test_reference_utility_launchers(api):
+    """Small reference launchers kept for launcher-level completeness (indexing.h:9-13, csr_impl.h:6-9, matrix_impl.h:17-26)."""
+    import ctypes as C
+    L = api.lib()
+    i32, vp, f64 = C.c_int32, C.c_void_p, C.c_double
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 7, 5000).astype(np.int32)
+    d = api.DeviceArray.from_numpy(data)
+    for fn in (L.CountValueI, L.CountValueColorLegacy):
+        fn.restype, fn.argtypes = i32, [vp, i32, i32]
+        assert fn(d.ptr, data.size, 3) == int((data == 3).sum())
+    L.CountValueColor.restype, L.CountValueColor.argtypes = i32, [vp, i32, i32, vp]
+    assert L.CountValueColor(d.ptr, data.size, 6, None) == int((data == 6).sum())
+    out = api.DeviceArray(int((data == 3).sum()), np.int32)
+    L.FindValueI.argtypes = [vp, i32, i32, vp]
+    L.FindValueI(d.ptr, data.size, 3, out.ptr)
+    api.sync()
+    assert np.array_equal(out.numpy(), np.nonzero(data == 3)[0])
+    # pattern lookups and scalar value setters on a small CSR pattern
+    m = kuhn_cube(3, jitter=0.0)
+    P = api.Problem(m, color=False)
+    try:
+        rp, ci = P.pattern()
+        nnz = ci.size
+        k = rng.integers(0, nnz, 400)
+        rows = (np.searchsorted(rp, k, side="right") - 1).astype(np.int32)
+        cols = ci[k].astype(np.int32)
+        cols[::50] = (cols[::50] + 1000) % P.N                      # some pairs that are (almost surely) not in the pattern
+        present = np.array([c in ci[rp[r]:rp[r + 1]] for r, c in zip(rows, cols)])
+        want = np.array([rp[r] + np.searchsorted(ci[rp[r]:rp[r + 1]], c) if ok else -1 for r, c, ok in zip(rows, cols, present)], np.int32)
+        r_d, c_d, ind_d = api.DeviceArray.from_numpy(rows), api.DeviceArray.from_numpy(cols), api.DeviceArray(rows.size, np.int32)
+        L.CSRAttrGetNZIndBatchedGPU.argtypes = [vp, i32, vp, vp, vp]
+        L.CSRAttrGetNZIndBatchedGPU(C.cast(P.spy1x1, vp), rows.size, r_d.ptr, c_d.ptr, ind_d.ptr)
+        api.sync()
+        assert np.array_equal(ind_d.numpy(), want)
+        vals0 = rng.normal(size=nnz)
+        upd = rng.normal(size=rows.size)
+        uniq = np.unique(want[want >= 0], return_index=True)[1]     # one update per nonzero: order-independent check
+        sel = np.nonzero(want >= 0)[0][uniq]
+        mv = api.DeviceArray.from_numpy(vals0)
+        rp_d, ci_d = api.DeviceArray.from_numpy(rp.astype(np.int32)), api.DeviceArray.from_numpy(ci.astype(np.int32))
+        rs, cs, us = (api.DeviceArray.from_numpy(np.ascontiguousarray(a[sel])) for a in (rows, cols, upd))
+        L.MatrixCSRSetValuesCOOGPU.argtypes = [vp, f64, i32, i32, vp, vp, i32, vp, vp, vp, f64]
+        L.MatrixCSRSetValuesCOOGPU(mv.ptr, 0.5, P.N, P.N, rp_d.ptr, ci_d.ptr, sel.size, rs.ptr, cs.ptr, us.ptr, 2.0)
+        api.sync()
+        exp = vals0.copy()
+        exp[want[sel]] = 0.5 * exp[want[sel]] + 2.0 * upd[sel]
+        assert np.array_equal(mv.numpy(), exp)
+        idx = api.DeviceArray.from_numpy(want[sel])
+        L.MatrixCSRSetValuesIndGPU.argtypes = [vp, f64, i32, vp, vp, f64]
+        L.MatrixCSRSetValuesIndGPU(mv.ptr, 0.0, sel.size, idx.ptr, us.ptr, 1.0)
+        api.sync()
+        exp[want[sel]] = upd[sel]
+        assert np.array_equal(mv.numpy(), exp)
+    finally:
+        P.close()
+
+
 def test_single_tet_all_faces(api, oracle_lib):
     """DBG_TET-like case (src/main.c:357-361): one element, face assembly on a chosen group."""
     m = single_tet()
