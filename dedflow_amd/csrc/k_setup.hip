@@ -14,19 +14,22 @@ namespace {
 
 constexpr int BLK = 256;
 
+// NSHL vertices per element: 4 tet, 6 prism, 8 hex (color_impl.cu:27-61 has one instantiation per element type)
+template <int NSHL>
 __global__ void v2e_count_kernel(const I* ien, I T_, I* row_ptr) {
     const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
     if (i >= T_) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(row_ptr + ien[i * 4 + j] + 1, 1);
+    for (int j = 0; j < NSHL; ++j) atomicAdd(row_ptr + ien[i * NSHL + j] + 1, 1);
 }
 
+template <int NSHL>
 __global__ void v2e_fill_kernel(const I* ien, I T_, const I* row_ptr, I* col, I* counter) {
     const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
     if (i >= T_) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const I node = ien[i * 4 + j];
+    for (int j = 0; j < NSHL; ++j) {
+        const I node = ien[i * NSHL + j];
         const int off = atomicAdd(counter + node, 1);
         col[row_ptr[node] + off] = (I)i;
     }
@@ -258,6 +261,28 @@ __global__ void set_values_ind_kernel(double* __restrict__ matval, double alpha,
 
 }  // namespace
 
+template <int NSHL>
+static void v2e_row(const I* ien, I T_, I N, I* row_ptr) {
+    DFL_GUARD(hipMemset(row_ptr, 0, sizeof(I) * (size_t)(N + 1)));
+    if (T_ > 0) v2e_count_kernel<NSHL><<<ceil_div(T_, BLK), BLK>>>(ien, T_, row_ptr);
+    size_t bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, bytes, row_ptr, row_ptr, (size_t)(N + 1), rocprim::plus<I>());
+    void* tmp = nullptr;
+    DFL_GUARD(hipMalloc(&tmp, bytes + 16));
+    DFL_GUARD(rocprim::inclusive_scan(tmp, bytes, row_ptr, row_ptr, (size_t)(N + 1), rocprim::plus<I>()));
+    DFL_GUARD(hipDeviceSynchronize());
+    DFL_GUARD(hipFree(tmp));
+}
+template <int NSHL>
+static void v2e_col(const I* ien, I T_, I N, const I* row_ptr, I* col_idx) {
+    if (T_ <= 0) return;
+    I* counter = nullptr;
+    DFL_GUARD(hipMalloc((void**)&counter, sizeof(I) * (size_t)N));
+    DFL_GUARD(hipMemset(counter, 0, sizeof(I) * (size_t)N));
+    v2e_fill_kernel<NSHL><<<ceil_div(T_, BLK), BLK>>>(ien, T_, row_ptr, col_idx, counter);
+    DFL_GUARD(hipDeviceSynchronize());
+    DFL_GUARD(hipFree(counter));
+}
 extern "C" {
 
 int64_t dfl_scan_temp_bytes(I n) {
@@ -276,26 +301,12 @@ void dfl_exclusive_scan_i32(I n, const I* len, I* ptr, void* temp, int64_t temp_
     DFL_LAUNCH_CHECK();
 }
 
-void GenerateV2EMapRowTetGPU(const I* ien, I T_, I N, I* row_ptr) {
-    DFL_GUARD(hipMemset(row_ptr, 0, sizeof(I) * (size_t)(N + 1)));
-    v2e_count_kernel<<<ceil_div(T_, BLK), BLK>>>(ien, T_, row_ptr);
-    size_t bytes = 0;
-    (void)rocprim::inclusive_scan(nullptr, bytes, row_ptr, row_ptr, (size_t)(N + 1), rocprim::plus<I>());
-    void* tmp = nullptr;
-    DFL_GUARD(hipMalloc(&tmp, bytes + 16));
-    DFL_GUARD(rocprim::inclusive_scan(tmp, bytes, row_ptr, row_ptr, (size_t)(N + 1), rocprim::plus<I>()));
-    DFL_GUARD(hipDeviceSynchronize());
-    DFL_GUARD(hipFree(tmp));
-}
-
-void GenerateV2EMapColTetGPU(const I* ien, I T_, I N, const I* row_ptr, I* col_idx) {
-    I* counter = nullptr;
-    DFL_GUARD(hipMalloc((void**)&counter, sizeof(I) * (size_t)N));
-    DFL_GUARD(hipMemset(counter, 0, sizeof(I) * (size_t)N));
-    v2e_fill_kernel<<<ceil_div(T_, BLK), BLK>>>(ien, T_, row_ptr, col_idx, counter);
-    DFL_GUARD(hipDeviceSynchronize());
-    DFL_GUARD(hipFree(counter));
-}
+void GenerateV2EMapRowTetGPU(const I* ien, I T_, I N, I* row_ptr) { v2e_row<4>(ien, T_, N, row_ptr); }
+void GenerateV2EMapColTetGPU(const I* ien, I T_, I N, const I* row_ptr, I* col_idx) { v2e_col<4>(ien, T_, N, row_ptr, col_idx); }
+void GenerateV2EMapRowPrismGPU(const I* ien, I E, I N, I* row_ptr) { v2e_row<6>(ien, E, N, row_ptr); }
+void GenerateV2EMapColPrismGPU(const I* ien, I E, I N, const I* row_ptr, I* col_idx) { v2e_col<6>(ien, E, N, row_ptr, col_idx); }
+void GenerateV2EMapRowHexGPU(const I* ien, I E, I N, I* row_ptr) { v2e_row<8>(ien, E, N, row_ptr); }
+void GenerateV2EMapColHexGPU(const I* ien, I E, I N, const I* row_ptr, I* col_idx) { v2e_col<8>(ien, E, N, row_ptr, col_idx); }
 
 void GenerateRandomColor(I* color, I n, I max_color) {
     if (n <= 0) return;

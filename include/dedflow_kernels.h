@@ -193,6 +193,12 @@ void dfl_elem_nzmap(dfl_index T, const dfl_index* ien_b, const dfl_index* row_pt
 void GenerateV2EMapRowTetGPU(const dfl_index* ien, dfl_index num_elem, dfl_index num_node, dfl_index* row_ptr);
 void GenerateV2EMapColTetGPU(const dfl_index* ien, dfl_index num_elem, dfl_index num_node, const dfl_index* row_ptr,
                              dfl_index* col_idx);
+/* prism (6 vertices) and hex (8) flavours of the same map (color_impl.h:12-16; those element types are otherwise empty
+ * in the reference and out of scope here) */
+void GenerateV2EMapRowPrismGPU(const dfl_index* ien, dfl_index num_elem, dfl_index num_node, dfl_index* row_ptr);
+void GenerateV2EMapColPrismGPU(const dfl_index* ien, dfl_index num_elem, dfl_index num_node, const dfl_index* row_ptr, dfl_index* col_idx);
+void GenerateV2EMapRowHexGPU(const dfl_index* ien, dfl_index num_elem, dfl_index num_node, dfl_index* row_ptr);
+void GenerateV2EMapColHexGPU(const dfl_index* ien, dfl_index num_elem, dfl_index num_node, const dfl_index* row_ptr, dfl_index* col_idx);
 void GenerateRandomColor(dfl_index* color, dfl_index num_elem, dfl_index max_color); /* XORWOW(1234), LEGACY ordering */
 void ColorElementJPLTetGPU(const dfl_index* ien, const dfl_index* row_ptr, const dfl_index* col_ind, dfl_index max_color,
                            dfl_index* color, dfl_index num_elem);

@@ -439,6 +439,22 @@ def test_reference_utility_launchers(api):
     L.FindValueI(d.ptr, data.size, 3, out.ptr)
     api.sync()
     assert np.array_equal(out.numpy(), np.nonzero(data == 3)[0])
+    # vertex -> element maps for 6- and 8-vertex elements (same kernels as the tet map)
+    for nshl, name in ((6, "Prism"), (8, "Hex")):
+        E, Nn = 300, 120
+        conn = np.stack([rng.permutation(Nn)[:nshl] for _ in range(E)]).astype(np.int32)
+        c_d = api.DeviceArray.from_numpy(conn.reshape(-1))
+        rp_d = api.DeviceArray(Nn + 1, np.int32)
+        getattr(L, "GenerateV2EMapRow%sGPU" % name).argtypes = [vp, i32, i32, vp]
+        getattr(L, "GenerateV2EMapRow%sGPU" % name)(c_d.ptr, E, Nn, rp_d.ptr)
+        rpv = rp_d.numpy()
+        assert np.array_equal(np.diff(rpv), np.bincount(conn.reshape(-1), minlength=Nn)) and rpv[-1] == E * nshl
+        col_d = api.DeviceArray(E * nshl, np.int32)
+        getattr(L, "GenerateV2EMapCol%sGPU" % name).argtypes = [vp, i32, i32, vp, vp]
+        getattr(L, "GenerateV2EMapCol%sGPU" % name)(c_d.ptr, E, Nn, rp_d.ptr, col_d.ptr)
+        colv = col_d.numpy()
+        for n in range(0, Nn, 7):
+            assert sorted(colv[rpv[n]:rpv[n + 1]]) == sorted(np.nonzero((conn == n).any(axis=1))[0])
     # pattern lookups and scalar value setters on a small CSR pattern
     m = kuhn_cube(3, jitter=0.0)
     P = api.Problem(m, color=False)
