@@ -290,6 +290,48 @@ __global__ void node_from_row_kernel(I n, I* node, I shape) {
     if (i < n) node[i] = node[i] / shape;
 }
 
+// SetBlockValueToSubmatGPU (matrix_impl.h:59-64, kernel matrix_impl.cu:370-453): the colored scatter of the reference --
+// one thread per (batch element, a, b); the (offset[i], offset[j]) sub-block of the lda-strided element block goes into
+// sub-matrix (i, j)'s row-expanded value array (NULL sub-matrices are skipped), m = alpha*m + beta*b.  Row-expanded
+// layout (csr_impl.cu:24-59): scalar row node*br + ii holds len*bc entries, entry (k - start)*bc + jj.
+__global__ __launch_bounds__(BLK) void block_to_submat_kernel(T* const* __restrict__ matval, T alpha, I n_offset,
+                                                             const I* __restrict__ offset, I nshl, I batch_size,
+                                                             const I* __restrict__ batch_index_ptr, const I* __restrict__ ien,
+                                                             const I* __restrict__ rp, const I* __restrict__ ci,
+                                                             const T* __restrict__ val, int lda, int stride, T beta,
+                                                             const I* __restrict__ mask) {
+    const long long idx = (long long)blockIdx.x * BLK + threadIdx.x;
+    const int n2 = nshl * nshl;
+    if (idx >= (long long)batch_size * n2) return;
+    const long long slot = idx / n2;
+    if (mask && mask[slot] == 0) return;
+    const long long iel = batch_index_ptr ? batch_index_ptr[slot] : slot;
+    const int aa = (int)(idx % n2) / nshl, bb = (int)(idx % nshl);
+    const I row = ien[iel * nshl + aa], col = ien[iel * nshl + bb];
+    const I start = rp[row], len = rp[row + 1] - start;
+    I lo = 0, hi = len - 1;  // ascending column indices inside a row
+    while (lo < hi) {
+        const I mid = (lo + hi) >> 1;
+        if (ci[start + mid] < col) lo = mid + 1; else hi = mid;
+    }
+    if (len <= 0 || ci[start + lo] != col) return;
+    const T* b = val + idx * stride;
+    for (I i = 0; i < n_offset; ++i) {
+        const I br = offset[i + 1] - offset[i];
+        for (I j = 0; j < n_offset; ++j) {
+            T* m = matval[i * n_offset + j];
+            if (!m) continue;
+            const I bc = offset[j + 1] - offset[j];
+            m += (long long)start * br * bc + (long long)lo * bc;
+            for (I ii = 0; ii < br; ++ii)
+                for (I jj = 0; jj < bc; ++jj) {
+                    T* dst = m + (long long)ii * len * bc + jj;
+                    *dst = alpha * *dst + beta * b[(offset[i] + ii) * lda + (offset[j] + jj)];
+                }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -317,6 +359,16 @@ void dfl_bcsr_spmv_range(I row0, I row1, I N, const I* rp, const I* ci, const T*
 }
 void dfl_bcsr_spmv_rows(I nrows, I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
     dfl_bcsr_spmv_range(0, nrows, N, rp, ci, val, alpha, x, beta, y, stream);
+}
+void SetBlockValueToSubmatGPU(T** matval, T alpha, I n_offset, const I* offset, I nshl, I batch_size, const I* batch_index_ptr,
+                              const I* ien, I num_row, I num_col, const I* rp, const I* ci, const T* val, int lda, int stride, T beta,
+                              const I* mask) {
+    (void)num_row; (void)num_col;
+    if (batch_size <= 0) return;
+    const long long nthread = (long long)batch_size * nshl * nshl;
+    block_to_submat_kernel<<<ceil_div(nthread, BLK), BLK>>>(matval, alpha, n_offset, offset, nshl, batch_size, batch_index_ptr, ien,
+                                                            rp, ci, val, lda, stride, beta, mask);
+    DFL_LAUNCH_CHECK();
 }
 /* kernel-variant selection for A/B measurements (key 0: block-CSR SpMV variant 0..4; 4 = default, XCD-aware row slabs) */
 void dfl_tune(int key, int value) {

@@ -211,6 +211,14 @@ dfl_index CountValueColor(const dfl_index* data, dfl_index n, dfl_index value, v
 /* positions of (row[i], col[i]) in a CSR pattern, -1 if absent (kernel behind CSRAttrGetNZIndBatchedGPU, csr_impl.h:7-9) */
 void dfl_csr_find_nz(dfl_index batch_size, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_index* row,
                      const dfl_index* col, dfl_index* ind, void* stream);
+/* matrix_impl.h:59-64: the reference's colored element-block scatter into the row-expanded sub-matrix arrays (a14).  The
+ * assembly kernels of this library scatter directly into the block array and never call it; it is exported for a host that
+ * keeps its own element kernels.  matval = DEVICE array of n_offset^2 device pointers (NULL = sub-matrix absent), offset =
+ * DEVICE array [n_offset+1]; one batch must be conflict-free (a color), as in the reference. */
+void SetBlockValueToSubmatGPU(dfl_value** matval, dfl_value alpha, dfl_index n_offset, const dfl_index* offset, dfl_index nshl,
+                              dfl_index batch_size, const dfl_index* batch_index_ptr, const dfl_index* ien, dfl_index num_row,
+                              dfl_index num_col, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val, int lda,
+                              int stride, dfl_value beta, const dfl_index* mask);
 /* matrix_impl.h:17-26 (scalar CSR value setters; off the hot path, kept for launcher-level completeness) */
 void MatrixCSRSetValuesCOOGPU(dfl_value* matval, dfl_value alpha, dfl_index num_row, dfl_index num_col, const dfl_index* row_ptr,
                               const dfl_index* col_ind, dfl_index n, const dfl_index* row, const dfl_index* col,

@@ -495,6 +495,59 @@ def test_reference_utility_launchers(api):
         P.close()
 
 
+def test_reference_block_scatter_launcher(api):
+    """SetBlockValueToSubmatGPU (matrix_impl.h:59-64), the reference's colored scatter, on one color batch against a numpy
+    restatement of the row-expanded layout (csr_impl.cu:24-59): scalar row node*br+ii, entry (k-start)*bc+jj."""
+    import ctypes as C
+    m = kuhn_cube(4, jitter=0.1)
+    P = api.Problem(m)
+    L = api.lib()
+    try:
+        rp, ci = P.pattern()
+        N, nnz = P.N, ci.size
+        color, off, ind = P.color(), P.batch_offset(), P.batch_ind()
+        batch = ind[off[2]:off[3]].astype(np.int32)                 # one color: conflict-free
+        rng = np.random.default_rng(11)
+        nshl, bs = 4, 6
+        val = rng.normal(size=(batch.size, nshl * nshl, bs * bs))   # stride 36, lda 6
+        offset = np.array([0, 3, 4, 5, 6], np.int32)
+        shapes = {(0, 0): (3, 3), (0, 1): (3, 1), (1, 0): (1, 3), (1, 1): (1, 1)}
+        arrays = {k: rng.normal(size=nnz * br * bc) for k, (br, bc) in shapes.items()}
+        dev = {k: api.DeviceArray.from_numpy(v) for k, v in arrays.items()}
+        ptrs = np.zeros(16, np.uint64)
+        for (i, j), d in dev.items():
+            ptrs[i * 4 + j] = d.ptr
+        ptr_d = api.DeviceArray.from_numpy(ptrs)
+        off_d, b_d, val_d = api.DeviceArray.from_numpy(offset), api.DeviceArray.from_numpy(batch), api.DeviceArray.from_numpy(val.reshape(-1))
+        ien_d = api.DeviceArray.from_numpy(m.ien)
+        rp_d, ci_d = api.DeviceArray.from_numpy(rp.astype(np.int32)), api.DeviceArray.from_numpy(ci.astype(np.int32))
+        vp, i32, f64 = C.c_void_p, C.c_int32, C.c_double
+        L.SetBlockValueToSubmatGPU.argtypes = [vp, f64, i32, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp, C.c_int, C.c_int, f64, vp]
+        alpha, beta = 0.75, 1.5
+        L.SetBlockValueToSubmatGPU(ptr_d.ptr, alpha, 4, off_d.ptr, nshl, batch.size, b_d.ptr, ien_d.ptr, N, N, rp_d.ptr, ci_d.ptr,
+                                   val_d.ptr, bs, bs * bs, beta, None)
+        api.sync()
+        exp = {k: v.copy() for k, v in arrays.items()}
+        ien = m.ien.reshape(-1, 4)
+        for s_, e in enumerate(batch):
+            for a in range(4):
+                for b in range(4):
+                    row, col = ien[e, a], ien[e, b]
+                    start, ln = rp[row], rp[row + 1] - rp[row]
+                    k = start + np.searchsorted(ci[start:start + ln], col)
+                    blk = val[s_, a * 4 + b].reshape(bs, bs)
+                    for (i, j), (br, bc) in shapes.items():
+                        base = start * br * bc + (k - start) * bc
+                        for ii in range(br):
+                            for jj in range(bc):
+                                p_ = base + ii * ln * bc + jj
+                                exp[(i, j)][p_] = alpha * exp[(i, j)][p_] + beta * blk[offset[i] + ii, offset[j] + jj]
+        for k_, d in dev.items():
+            assert np.allclose(d.numpy(), exp[k_], rtol=0, atol=1e-14), k_
+    finally:
+        P.close()
+
+
 def test_single_tet_all_faces(api, oracle_lib):
     """DBG_TET-like case (src/main.c:357-361): one element, face assembly on a chosen group."""
     m = single_tet()
