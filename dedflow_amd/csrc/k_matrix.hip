@@ -290,6 +290,21 @@ __global__ void node_from_row_kernel(I n, I* node, I shape) {
     if (i < n) node[i] = node[i] / shape;
 }
 
+// scalar-CSR point Jacobi, y_i = x_i / a_ii (pc_impl.cu:7-40; y may alias x for the in-place form).  Rows without a stored
+// diagonal are left untouched, as in the reference.
+__global__ __launch_bounds__(BLK) void csr_jacobi_kernel(I n, const T* __restrict__ data, const I* __restrict__ rp,
+                                                        const I* __restrict__ ci, const T* x, T* y) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    I lo = rp[i], hi = rp[i + 1] - 1;
+    if (lo > hi) return;
+    while (lo < hi) {
+        const I mid = (lo + hi) >> 1;
+        if (ci[mid] < (I)i) lo = mid + 1; else hi = mid;
+    }
+    if (ci[lo] == (I)i) y[i] = x[i] / data[lo];
+}
+
 // SetBlockValueToSubmatGPU (matrix_impl.h:59-64, kernel matrix_impl.cu:370-453): the colored scatter of the reference --
 // one thread per (batch element, a, b); the (offset[i], offset[j]) sub-block of the lda-strided element block goes into
 // sub-matrix (i, j)'s row-expanded value array (NULL sub-matrices are skipped), m = alpha*m + beta*b.  Row-expanded
@@ -359,6 +374,14 @@ void dfl_bcsr_spmv_range(I row0, I row1, I N, const I* rp, const I* ci, const T*
 }
 void dfl_bcsr_spmv_rows(I nrows, I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
     dfl_bcsr_spmv_range(0, nrows, N, rp, ci, val, alpha, x, beta, y, stream);
+}
+void PCJacobiDevice(I n, I nnz, double* data, I* rp, I* ci, double* x, double* y) {  // pc_impl.h:6
+    (void)nnz;
+    if (n > 0) csr_jacobi_kernel<<<ceil_div(n, BLK), BLK>>>(n, data, rp, ci, x, y);
+    DFL_LAUNCH_CHECK();
+}
+void PCJacobiInplaceDevice(I n, I nnz, double* data, I* rp, I* ci, double* x) {  // pc_impl.h:7
+    PCJacobiDevice(n, nnz, data, rp, ci, x, x);
 }
 void SetBlockValueToSubmatGPU(T** matval, T alpha, I n_offset, const I* offset, I nshl, I batch_size, const I* batch_index_ptr,
                               const I* ien, I num_row, I num_col, const I* rp, const I* ci, const T* val, int lda, int stride, T beta,

@@ -211,6 +211,9 @@ dfl_index CountValueColor(const dfl_index* data, dfl_index n, dfl_index value, v
 /* positions of (row[i], col[i]) in a CSR pattern, -1 if absent (kernel behind CSRAttrGetNZIndBatchedGPU, csr_impl.h:7-9) */
 void dfl_csr_find_nz(dfl_index batch_size, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_index* row,
                      const dfl_index* col, dfl_index* ind, void* stream);
+/* pc_impl.h:6-7: point Jacobi on a scalar CSR matrix, y = x / diag(A) (in place: x /= diag(A)) */
+void PCJacobiDevice(dfl_index n, dfl_index nnz, dfl_value* data, dfl_index* row_ptr, dfl_index* col_idx, dfl_value* x, dfl_value* y);
+void PCJacobiInplaceDevice(dfl_index n, dfl_index nnz, dfl_value* data, dfl_index* row_ptr, dfl_index* col_idx, dfl_value* x);
 /* matrix_impl.h:59-64: the reference's colored element-block scatter into the row-expanded sub-matrix arrays (a14).  The
  * assembly kernels of this library scatter directly into the block array and never call it; it is exported for a host that
  * keeps its own element kernels.  matval = DEVICE array of n_offset^2 device pointers (NULL = sub-matrix absent), offset =

@@ -485,6 +485,19 @@ def test_reference_utility_launchers(api):
         exp = vals0.copy()
         exp[want[sel]] = 0.5 * exp[want[sel]] + 2.0 * upd[sel]
         assert np.array_equal(mv.numpy(), exp)
+        # point Jacobi on the scalar pattern (pc_impl.h:6-7)
+        dvals = rng.uniform(1.0, 2.0, nnz)
+        dv, xv, yv = api.DeviceArray.from_numpy(dvals), api.DeviceArray.from_numpy(rng.normal(size=P.N)), api.DeviceArray(P.N)
+        diag = np.array([dvals[rp[i] + np.searchsorted(ci[rp[i]:rp[i + 1]], i)] for i in range(P.N)])
+        L.PCJacobiDevice.argtypes = [i32, i32, vp, vp, vp, vp, vp]
+        L.PCJacobiDevice(P.N, nnz, dv.ptr, rp_d.ptr, ci_d.ptr, xv.ptr, yv.ptr)
+        api.sync()
+        x_host = xv.numpy()
+        assert np.array_equal(yv.numpy(), x_host / diag)
+        L.PCJacobiInplaceDevice.argtypes = [i32, i32, vp, vp, vp, vp]
+        L.PCJacobiInplaceDevice(P.N, nnz, dv.ptr, rp_d.ptr, ci_d.ptr, xv.ptr)
+        api.sync()
+        assert np.array_equal(xv.numpy(), x_host / diag)
         idx = api.DeviceArray.from_numpy(want[sel])
         L.MatrixCSRSetValuesIndGPU.argtypes = [vp, f64, i32, vp, vp, f64]
         L.MatrixCSRSetValuesIndGPU(mv.ptr, 0.0, sel.size, idx.ptr, us.ptr, 1.0)
