@@ -324,13 +324,34 @@ __global__ __launch_bounds__(BLK) void norm_givens_kernel(int npart, const T* pa
     givens_step_block(iter, s_nrm, H, ldh, gv, beta, res_hist, s_col, s_gv);
 }
 
-__global__ void gmres_trsv_kernel(I m, const T* H, I ldh, T* beta) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// H[0:m,0:m] y = beta by back substitution (cublasDtrsv, krylov.c:297-301), one workgroup: column-oriented so that every
+// step is one coalesced column update (a single thread walking rows pays a dependent global load per entry: 85 us at m = 40)
+template <bool STAGED>
+__global__ __launch_bounds__(BLK) void gmres_trsv_kernel(I m, const T* __restrict__ H, I ldh, T* __restrict__ beta) {
+    extern __shared__ double s_mem[];  // [m] right-hand side, then (STAGED) the m x m upper triangle, column-major
+    __shared__ double s_y;
+    double* s_b = s_mem;
+    double* s_H = s_mem + m;
+    const int t = threadIdx.x;
+    for (int i = t; i < m; i += BLK) s_b[i] = beta[i];
+    if (STAGED)
+        for (int k = t; k < m * m; k += BLK) {
+            const int c = k / m, r = k - c * m;
+            s_H[k] = H[(long long)c * ldh + r];
+        }
+    __syncthreads();
     for (I i = m - 1; i >= 0; --i) {
-        double s = beta[i];
-        for (I j = i + 1; j < m; ++j) s -= H[(long long)j * ldh + i] * beta[j];
-        beta[i] = s / H[(long long)i * ldh + i];
+        const T* col = STAGED ? s_H + (long long)i * m : H + (long long)i * ldh;  // H(r, i), r <= i: contiguous
+        if (t == 0) {
+            s_y = s_b[i] / col[i];
+            s_b[i] = s_y;
+        }
+        __syncthreads();
+        const double y = s_y;
+        for (int r = t; r < i; r += BLK) s_b[r] -= col[r] * y;
+        __syncthreads();
     }
+    for (int i = t; i < m; i += BLK) beta[i] = s_b[i];
 }
 
 __global__ void sqrt_kernel(T* v) { v[0] = sqrt(v[0]); }
@@ -473,7 +494,10 @@ void dfl_gmres_givens_pythagoras(I iter, T* d_nrm, T* d_H, I ldh, T* d_gv, T* d_
     DFL_LAUNCH_CHECK();
 }
 void dfl_gmres_trsv(I m, const T* d_H, I ldh, T* d_beta, void* stream) {
-    gmres_trsv_kernel<<<1, 64, 0, S(stream)>>>(m, d_H, ldh, d_beta);
+    if (m <= 0) return;
+    const size_t staged = ((size_t)m * m + m) * sizeof(double);
+    if (staged <= 60 * 1024) gmres_trsv_kernel<true><<<1, BLK, staged, S(stream)>>>(m, d_H, ldh, d_beta);
+    else gmres_trsv_kernel<false><<<1, BLK, (size_t)m * sizeof(double), S(stream)>>>(m, d_H, ldh, d_beta);
     DFL_LAUNCH_CHECK();
 }
 void GMRESResidualUpdatePrivate(T* beta, T* gv) {
