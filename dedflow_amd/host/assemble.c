@@ -27,6 +27,9 @@ void DflSetRhsPatchParameters(index_type leaf_tets, index_type node_cap) {
     if (leaf_tets > 0 && leaf_tets <= dfl_rhs_patch_max_tets()) g_rhspatch_leaf = leaf_tets;
     if (node_cap >= 4 && node_cap <= dfl_rhs_patch_max_nodes()) g_rhspatch_nodes = node_cap;
 }
+/* boundary group whose faces carry the weak-BC terms (the reference hard-codes group 4) */
+static index_type g_face_group = 4;
+void DflSetWeakBCGroup(index_type group) { g_face_group = group; }
 void DflSetQuiet(b32 quiet) { g_quiet = quiet; }
 /* node coordinates were modified (moving mesh): drop the per-element geometry cache, rebuilt at the next assembly */
 void DflMeshGeometryChanged(Mesh3D* mesh) {
@@ -145,7 +148,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
 }
 
 void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J) {
-    const index_type group = 4; /* assemble.cu:1826-1828 */
+    const index_type group = g_face_group; /* 4 in the reference, hard-coded at assemble.cu:1826-1828 */
     const Mesh3DData* dev = Mesh3DDevice(mesh);
     const index_type N = Mesh3DNumNode(mesh);
     hipStream_t s = DflStream();

@@ -437,6 +437,9 @@ index_type DflTimeStep(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* 
 void DflMeshGeometryChanged(Mesh3D* mesh);
 /* device memory pool of the default DEVICE allocator (host/runtime.c; DFL_DEVICE_POOL_GB=0 disables it) */
 void DflDevicePoolStats(int64_t* reserved_bytes, int64_t* in_use_bytes);
+/* boundary group whose faces get the weak-BC terms of AssembleSystemTetFace (default 4 = the reference's hard-coded group,
+ * assemble.cu:1826-1828); lists are rebuilt when the group changes */
+void DflSetWeakBCGroup(index_type group);
 void DflSetQuiet(b32 quiet); /* suppress the reference's stdout chatter ("Assemble: F J", timers) */
 /* which conflict-free launches the assembly kernels execute (set BEFORE Mesh3DGenerateColorBatch):
  *   0  the reference's JPL color batches, one launch per color (reference summation order)

@@ -9,6 +9,7 @@ cancel to ~0 cannot be compared entry-relative).
 The oracle itself is "parity unpinned" w.r.t. the real reference (no runnable
 reference, no fixtures -- SURVEY.md F7).
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -559,6 +560,37 @@ def test_reference_block_scatter_launcher(api):
             assert np.allclose(d.numpy(), exp[k_], rtol=0, atol=1e-14), k_
     finally:
         P.close()
+
+
+@pytest.mark.parametrize("group", [1, 4])
+def test_weak_bc_faces_on_a_chosen_group(api, oracle_lib, group):
+    """AssembleSystemTetFace on boundary group 4 (the reference's hard-coded group) and on another group through
+    DflSetWeakBCGroup: residual and Jacobian face terms against the oracle's face assembly of the same group."""
+    m = kuhn_cube(5, jitter=0.2)
+    S = oracle_lib.System(m)
+    wg, dwg = synthetic_fields(m)
+    L = api.lib()
+    L.DflSetWeakBCGroup.argtypes = [C.c_int32]
+    L.DflSetWeakBCGroup(group)
+    P = api.Problem(m, bcs=[])
+    try:
+        wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+        F_d = api.DeviceArray(6 * S.N)
+        L.MatrixZero(P.J)
+        P.assemble_face(wg_d, dwg_d, F_d, want_J=True)
+        api.sync()
+        F = np.zeros(6 * S.N)
+        vals = S.new_values()
+        S.assemble_face(wg, dwg, F, vals, group=group)
+        assert np.abs(F).max() > 0
+        ok, err = close(F_d.numpy(), F)
+        assert ok, err
+        for g, o in zip(P.export_values(), vals):
+            ok, err = close(g, o)
+            assert ok, err
+    finally:
+        P.close()
+        L.DflSetWeakBCGroup(4)
 
 
 def test_single_tet_all_faces(api, oracle_lib):
