@@ -27,7 +27,7 @@ $(H5LIB): dedflow_amd/h5/h5io.c include/dedflow.h $(LIB)
 	    -Wl,-rpath,$(HDF5)/lib -Wl,-rpath,'$$ORIGIN'; \
 	else echo "HDF5 headers not found under $(HDF5): skipping $@"; fi
 
-dedflow_amd/csrc/%.o: dedflow_amd/csrc/%.hip dedflow_amd/csrc/dfl_common.hpp include/dedflow_kernels.h
+dedflow_amd/csrc/%.o: dedflow_amd/csrc/%.hip dedflow_amd/csrc/dfl_common.hpp dedflow_amd/csrc/asm_device.hpp include/dedflow_kernels.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 dedflow_amd/host/%.o: dedflow_amd/host/%.c include/dedflow.h include/dedflow_kernels.h dedflow_amd/host/host_private.h

@@ -260,6 +260,7 @@ def _declare(L):
     f("DflStream", vp, []); f("DflSetStream", None, [vp]); f("DflSetQuiet", None, [i32])
     f("DflSetAssemblySchedule", None, [C.c_int]); f("DflSetPatchParameters", None, [i32, i32])
     f("DflSetRowPatchParameters", None, [i32, i32]); f("dfl_tune_asm", None, [C.c_int])
+    f("DflSetSlotPatchParameters", None, [i32, i32, i32]); f("DflSetRhsWaveParameters", None, [i32, i32])
     f("DflSetRhsPatchParameters", None, [i32, i32]); f("DflMeshGeometryChanged", None, [C.POINTER(Mesh3D)])
     f("Mesh3DCreate", C.POINTER(Mesh3D), [i32, i32, i32, i32]); f("Mesh3DDestroy", None, [C.POINTER(Mesh3D)])
     f("Mesh3DUpdateDevice", None, [C.POINTER(Mesh3D)]); f("Mesh3DGenerateColorBatch", None, [C.POINTER(Mesh3D)])
@@ -282,7 +283,7 @@ def _declare(L):
     f("KrylovSetVerbose", None, [vp, i32]); f("KrylovSetComm", None, [vp, C.POINTER(DflComm)])
     f("PCSetup", None, [vp]); f("PCApply", None, [vp, vp, vp]); f("PCDestroy", None, [vp])
     f("PCCreateDILU", vp, [C.POINTER(Matrix)]); f("PCDILUGetColors", i32, [vp, vp]); f("PCDILUGetInverseBlocks", vp, [vp])
-    f("KrylovSetPCType", None, [vp, C.c_int]); f("KrylovGetPC", vp, [vp]); f("KrylovSetFusedNorm", None, [vp, C.c_int])
+    f("KrylovSetPCType", None, [vp, C.c_int]); f("KrylovGetPC", vp, [vp]); f("KrylovSetFusedNorm", None, [vp, C.c_int]); f("KrylovSetRestart", None, [vp, i32])
     f("AssembleSystemTet", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix)])
     f("AssembleSystemTetFace", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix)])
     f("AssembleSystem", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix), vp, i32])

@@ -1,0 +1,292 @@
+// Owner-computes assembly kernels for gfx950 (assembly schedule 4, the default):
+//
+//   tet_lhs_slot_kernel   Jacobian: one workgroup per spatial patch of nodes owns their CSR rows.  Phase 1 evaluates,
+//                         once per tet touching the patch, everything the sixteen (a,b) blocks of that tet share
+//                         (shape gradients, |det J|, convective shape derivatives and stabilisation parameters at the four
+//                         quadrature points; src/assemble.cu:528-603) into an LDS record.  Phase 2 gives every nodal
+//                         nonzero ("slot") of the owned rows to one lane quad: each lane walks a quarter of the slot's
+//                         (tet, a, b) contribution list (host/slotpatch.c), evaluates those blocks (assemble.cu:618-661)
+//                         from the LDS records and adds them up in registers; one DPP reduce-scatter inside the quad,
+//                         then the 128-byte block line is written ONCE (val = beta * val + sum).
+//                         No atomics anywhere, fixed summation order => bitwise reproducible like the reference's colored
+//                         scatter (matrix_impl.cu:370-453), at one launch instead of one per color.
+//
+// HBM view: every block line written once (128 B x nnz1) + slot map (4 B) + contribution descriptors (2 B x 16 T)
+// + patch-tet connectivity (16 B per patch-tet); node records are gathered through L2.  Compute: 16 block evaluations
+// per tet (the same count as the reference's kernel), the per-tet part once per (patch, tet) pair instead of 16 times.
+#include "asm_device.hpp"
+
+namespace {
+
+constexpr int SBLK = 256;
+constexpr int SP_RS = 34;  // doubles per LDS tet record: shg[12] conv[a][q] (16) tauM[4] sum tauC, detJ
+
+typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
+
+// Dynamic LDS of one workgroup: [max_tets] tet records | [max_slots + 1] contribution offsets (relative to the patch) |
+// [max_slots] nodal nonzero of each slot | [max_contrib] contribution descriptors -- the three lists are staged with
+// coalesced loads while the node records of phase 1 are in flight, so phase 2 never waits on HBM.
+__host__ __device__ inline size_t slot_lds_bytes(int max_tets, int max_slots, int max_contrib) {
+    return (size_t)max_tets * SP_RS * 8 + (size_t)(((2 * max_slots + 1) * 4 + 15) & ~15) + (size_t)((max_contrib * 2 + 15) & ~15);
+}
+
+// PROBE = true only under dfl_tune_asm (developer phase split: bit 0 skip phase 2, bit 1 skip phase 1, bit 2 skip the
+// block evaluation, bit 3 skip the store); the shipped instantiation carries no probe branches
+template <bool BETA0, bool PROBE>
+__global__ __launch_bounds__(SBLK) void tet_lhs_slot_kernel(I P, const int4* __restrict__ hdr, const int4* __restrict__ ptet_ien,
+                                                           const I* __restrict__ slot_nz, const I* __restrict__ coff,
+                                                           const unsigned short* __restrict__ desc,
+                                                           const T* __restrict__ nodep, T* __restrict__ val, T beta,
+                                                           int max_tets, int max_slots, int dbg_in) {
+    const int dbg = PROBE ? dbg_in : 0;
+    extern __shared__ __attribute__((aligned(16))) double s_tet[];
+    int* s_coff = reinterpret_cast<int*>(s_tet + (size_t)max_tets * SP_RS);
+    int* s_nz = s_coff + max_slots + 1;
+    unsigned short* s_desc = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(s_coff) + (((2 * max_slots + 1) * 4 + 15) & ~15));
+    // XCD-aware order: workgroup w runs on XCD w % 8; every XCD gets one contiguous range of the spatially ordered
+    // patches, so neighbouring patches (which share tets and node records) share an L2
+    const int per = (P + 7) >> 3;
+    const int pid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (pid >= P) return;
+    const int t = threadIdx.x;
+    const int4 h = hdr[2 * pid], h2 = hdr[2 * pid + 1];
+    const int t0 = h.x, nt = h.y, s0 = h.z, ns = h.w, c0 = h2.x, nc = h2.y;
+
+    // hop 2 of the load chain: connectivity of this lane's tet next to the three lists of the patch
+    int4 nd = make_int4(0, 0, 0, 0);
+    if (t < nt) nd = ptet_ien[t0 + t];
+    for (int k = t; k <= ns; k += SBLK) s_coff[k] = coff[s0 + k] - c0;
+    for (int k = t; k < ns; k += SBLK) s_nz[k] = slot_nz[s0 + k];
+    {   // c0 is a multiple of 4 descriptors (8 bytes)
+        const uint2* src = reinterpret_cast<const uint2*>(desc + c0);
+        uint2* dst = reinterpret_cast<uint2*>(s_desc);
+        for (int k = t; k < (nc + 3) >> 2; k += SBLK) dst[k] = src[k];
+    }
+
+    // ---- phase 1: one lane per (patch, tet) ------------------------------------------------------------------
+    for (int lt = t; lt < ((dbg & 2) ? 0 : nt); lt += SBLK) {
+        if (lt >= SBLK) nd = ptet_ien[t0 + lt];
+        const int node[4] = {nd.x, nd.y, nd.z, nd.w};
+        double x[12], u[12];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {  // packed node record: x at [0..2], u at [3..5]
+            const double2* r = reinterpret_cast<const double2*>(nodep + (long long)node[b] * 16);
+            const double2 v0 = r[0], v1 = r[1], v2 = r[2];
+            x[b * 3] = v0.x; x[b * 3 + 1] = v0.y; x[b * 3 + 2] = v1.x;
+            u[b * 3] = v1.y; u[b * 3 + 1] = v2.x; u[b * 3 + 2] = v2.y;
+        }
+        double invJ[9], shg[12], G[9], detJ;
+        tet_geometry(x, invJ, detJ, shg);
+        tet_metric(shg, G);
+        double gg = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gg += G[k] * G[k];
+        const double itr = 1.0 / (G[0] + G[4] + G[8]);
+        double* rec = s_tet + lt * SP_RS;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) rec[k] = shg[k];
+        double su[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) su[d] = ((u[d] + u[3 + d]) + u[6 + d]) + u[9 + d];
+        const double knu = kMU / kRHO;
+        double s_t1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // u at quadrature point q (qr_wgalpha, :1648-1655): shl(b,q) = SHB + (SHA-SHB)[b == q]
+            double uq[3], cv[4];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) uq[d] = SHB * su[d] + (SHA - SHB) * u[q * 3 + d];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {  // shconv (:574-583)
+                cv[a] = shg[a * 3] * uq[0] + shg[a * 3 + 1] * uq[1] + shg[a * 3 + 2] * uq[2];
+                rec[12 + a * 4 + q] = cv[a];
+            }
+            // |J^-1 u|^2 (rows of J^-1 = shape gradients of nodes 1..3) and the stabilisation parameters (:587-603)
+            const double y = cv[1] * cv[1] + cv[2] * cv[2] + cv[3] * cv[3] + (3.0 * knu * knu) * gg;
+            rec[28 + q] = rsqrt(4.0 / (kDT * kDT) + y) * (1.0 / kRHO);
+            s_t1 += y * rsqrt(y) * itr;  // tauC enters the block only through its sum over the quadrature points
+        }
+        rec[32] = s_t1;
+        rec[33] = detJ;
+    }
+    __syncthreads();
+    if (dbg & 1) return;
+
+    // ---- phase 2: one lane quad per slot -------------------------------------------------------------------------
+    const int j = t & 3;
+    const bool hi2 = (j >> 1) != 0, hi1 = (j & 1) != 0;
+    for (int sq = t >> 2; sq < ns; sq += SBLK / 4) {
+        const int cb0 = s_coff[sq], cb1 = s_coff[sq + 1];
+        const long long nz = s_nz[sq];
+        double acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+        for (int c = cb0 + j; c < cb1; c += 4) {
+            const int d = s_desc[c];
+            const int aa = (d >> 2) & 3, bb = d & 3;
+            const double* rec = s_tet + (d >> 4) * SP_RS;
+            double ga[3], gb[3], t0q[4], ca[4], cb[4];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ga[k] = rec[aa * 3 + k];
+                gb[k] = rec[bb * 3 + k];
+            }
+            const d2a* r2 = reinterpret_cast<const d2a*>(rec);
+            const d2a ca01 = r2[6 + aa * 2], ca23 = r2[7 + aa * 2], cb01 = r2[6 + bb * 2], cb23 = r2[7 + bb * 2];
+            const d2a ta01 = r2[14], ta23 = r2[15], sc = r2[16];
+            ca[0] = ca01.x; ca[1] = ca01.y; ca[2] = ca23.x; ca[3] = ca23.y;
+            cb[0] = cb01.x; cb[1] = cb01.y; cb[2] = cb23.x; cb[3] = cb23.y;
+            t0q[0] = ta01.x; t0q[1] = ta01.y; t0q[2] = ta23.x; t0q[3] = ta23.y;
+            if (PROBE && (dbg & 4)) {
+                acc[0] += ga[0] + gb[1] + ca[2] + cb[3] + t0q[0] + sc.x + sc.y;
+                continue;
+            }
+            double Bk[16];
+            lhs_block_eval_s(aa, bb, ga, gb, sc.y, t0q, sc.x, ca, cb, Bk);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += Bk[i];
+        }
+        // reduce-scatter inside the quad: lane j ends up with entries {2j, 2j+1, 8+2j, 9+2j} summed over the 4 lanes
+        double r8[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r8[i] = (hi2 ? acc[i + 4] : acc[i]) + dpp_quad<0x4E>(hi2 ? acc[i] : acc[i + 4]);
+            r8[4 + i] = (hi2 ? acc[i + 12] : acc[i + 8]) + dpp_quad<0x4E>(hi2 ? acc[i + 8] : acc[i + 12]);
+        }
+        double2 e0, e1;
+        e0.x = (hi1 ? r8[2] : r8[0]) + dpp_quad<0xB1>(hi1 ? r8[0] : r8[2]);
+        e0.y = (hi1 ? r8[3] : r8[1]) + dpp_quad<0xB1>(hi1 ? r8[1] : r8[3]);
+        e1.x = (hi1 ? r8[6] : r8[4]) + dpp_quad<0xB1>(hi1 ? r8[4] : r8[6]);
+        e1.y = (hi1 ? r8[7] : r8[5]) + dpp_quad<0xB1>(hi1 ? r8[5] : r8[7]);
+        if (PROBE && (dbg & 8)) { if (e0.x == 1.2345e300) val[nz] = e0.x + e0.y + e1.x + e1.y; continue; }
+        double2* dst = reinterpret_cast<double2*>(val + nz * 16) + j;
+        if (!BETA0) {
+            const double2 o0 = dst[0], o1 = dst[4];
+            e0.x += beta * o0.x; e0.y += beta * o0.y;
+            e1.x += beta * o1.x; e1.y += beta * o1.y;
+        }
+        dst[0] = e0;
+        dst[4] = e1;
+    }
+}
+
+// ====================================================================================
+//  Residual, wave-per-patch form (schedule 4).  Same arithmetic as tet_rhs_patch_kernel (k_assemble.hip): 4 lanes per
+//  tet (lane = vertex for the result, quadrature point for the weak form; assemble.cu:761-924), node records staged in
+//  LDS once per patch, per-(tet, vertex) results summed per patch node in adjacency order, one partial record per patch
+//  node.  What changes is the schedule: ONE WAVE owns a patch of <= TETS tets / <= NODES nodes, everything it shares is
+//  wave-local (no workgroup barrier), and the padded layout of host/patch.c makes every index list of a patch
+//  addressable from the patch id, so the loads of a patch are a two-hop chain (lists -> node records).  Many independent
+//  waves per CU then hide those two hops.
+// ====================================================================================
+template <int TETS, int NODES>
+__global__ __launch_bounds__(256) void tet_rhs_wave_kernel(I P, const I* __restrict__ cnt, const I* __restrict__ pnode,
+                                                          const unsigned char* __restrict__ lien,
+                                                          const unsigned short* __restrict__ adj,
+                                                          const unsigned short* __restrict__ adj_start,
+                                                          const T* __restrict__ nodep, T* __restrict__ partial) {
+    constexpr int RS = NV + 1;  // padded record
+    __shared__ double s_rec[4][NODES][RS];
+    __shared__ double s_out[4][6][TETS * 4];
+    __shared__ unsigned short s_adj[4][TETS * 4];
+    __shared__ unsigned short s_st[4][NODES + 2];
+    __shared__ int s_node[4][NODES];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // XCD-aware order over waves: workgroup b runs on XCD b % 8; every XCD gets one contiguous range of patches
+    const int per = ((P + 31) >> 5) << 2;  // patches per XCD, a multiple of 4
+    const int pid = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + w;
+    if (pid >= P) return;  // whole waves leave; nothing below synchronises across waves
+    const int c = cnt[pid];
+    const int ne = c & 0xffff, nn = c >> 16;
+    const long long e0 = (long long)pid * TETS, n0 = (long long)pid * NODES;
+    // hop 1: every list of the patch, addressed from the patch id
+    if (lane < nn) s_node[w][lane] = pnode[n0 + lane];
+    uchar4 lnv[TETS / 16];
+#pragma unroll
+    for (int ps = 0; ps < TETS / 16; ++ps) lnv[ps] = *reinterpret_cast<const uchar4*>(lien + (e0 + ps * 16 + (lane >> 2)) * 4);
+    for (int k = lane; k < ne * 4; k += 64) s_adj[w][k] = adj[e0 * 4 + k];
+    for (int k = lane; k <= nn; k += 64) s_st[w][k] = adj_start[n0 + pid + k];
+    WAVE_SYNC();
+    // hop 2: node records, 7 x 16 B per node
+    for (int k = lane; k < nn * 7; k += 64) {
+        const int ln = k / 7, part = k - ln * 7;
+        const long long node = s_node[w][ln];
+        const double2 v = reinterpret_cast<const double2*>(nodep + node * NREC)[part];
+        s_rec[w][ln][2 * part] = v.x;
+        s_rec[w][ln][2 * part + 1] = v.y;
+    }
+    WAVE_SYNC();
+    const int a = lane & 3;
+#pragma unroll
+    for (int ps = 0; ps < TETS / 16; ++ps) {
+        const int le = ps * 16 + (lane >> 2);
+        if (le < ne) {  // whole quads
+            const double* r[4] = {s_rec[w][lnv[ps].x], s_rec[w][lnv[ps].y], s_rec[w][lnv[ps].z], s_rec[w][lnv[ps].w]};
+            double mine[6];
+            rhs_quad(r, a, mine);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s_out[w][j][le * 4 + a] = mine[j];
+        }
+    }
+    WAVE_SYNC();
+    // ordered sum per patch node: contributions in ascending local tet order
+    for (int k = lane; k < nn * 6; k += 64) {
+        const int ln = k / 6, j = k - ln * 6;
+        double sum = 0.0;
+        for (int q = s_st[w][ln]; q < s_st[w][ln + 1]; ++q) sum += s_out[w][j][s_adj[w][q]];
+        partial[n0 * 6 + k] = sum;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dfl_lhs_slot_record_bytes(void) { return SP_RS * (int)sizeof(double); }
+int64_t dfl_lhs_slot_lds_bytes(I max_tets, I max_slots, I max_contrib) { return (int64_t)slot_lds_bytes(max_tets, max_slots, max_contrib); }
+
+extern int g_patch_dbg;
+void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const I* ptet_ien, const I* slot_nz, const I* coff,
+                               const unsigned short* desc, const T* nodep, T* val, T beta, I max_tets, I max_slots,
+                               I max_contrib, void* stream) {
+    if (npatch <= 0) return;
+    const size_t lds = slot_lds_bytes(max_tets, max_slots, max_contrib);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    const int grid = 8 * ((npatch + 7) / 8);
+    const int4* h4 = reinterpret_cast<const int4*>(hdr);
+    const int4* pi4 = reinterpret_cast<const int4*>(ptet_ien);
+    if (g_patch_dbg)
+        tet_lhs_slot_kernel<true, true><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, g_patch_dbg);
+    else if (beta == 0.0)
+        tet_lhs_slot_kernel<true, false><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, 0);
+    else
+        tet_lhs_slot_kernel<false, false><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, 0);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_assemble_tet_rhs_wave(I npatch, I pad_tets, I pad_nodes, const I* cnt, const I* pnode, const unsigned char* lien,
+                                const unsigned short* adj, const unsigned short* adj_start, const T* nodep, T* partial,
+                                void* stream) {
+    if (npatch <= 0) return;
+    const int per = ((npatch + 31) >> 5) << 2;
+    const int grid = 8 * (per / 4);
+    if (pad_tets == 32 && pad_nodes == 48)
+        tet_rhs_wave_kernel<32, 48><<<grid, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial);
+    else if (pad_tets == 64 && pad_nodes == 64)
+        tet_rhs_wave_kernel<64, 64><<<grid, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial);
+    else if (pad_tets == 16 && pad_nodes == 32)
+        tet_rhs_wave_kernel<16, 32><<<grid, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial);
+    else {
+        fprintf(stderr, "dfl_assemble_tet_rhs_wave: unsupported patch shape %d tets / %d nodes\n", (int)pad_tets, (int)pad_nodes);
+        abort();
+    }
+    DFL_LAUNCH_CHECK();
+}
+
+}  // extern "C"

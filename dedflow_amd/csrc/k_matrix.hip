@@ -26,7 +26,11 @@ __device__ __forceinline__ d2v ld_val(const d2v* p) {
 
 // U nodal nonzeros per loop trip: all U index loads, then all U value loads, then the 2U
 // gathers are issued before the first FMA -- more bytes in flight per 8-lane row group
-template <bool BETA0, bool NT, int U, bool XCD = false>
+// STORE: 0 = every row group stores its 4 results itself (3 x 8 B + 8 B per row: two partial 128-B lines per wave
+//            instruction), 1 = developer probe without the store, 2 = as 0 with nontemporal stores,
+//        3 = the 32 rows of a workgroup are staged in LDS and written by ONE wave instruction as whole lines
+//            (48 lanes x 16 B of the velocity part + 16 lanes x 16 B of the pressure part)
+template <bool BETA0, bool NT, int U, bool XCD = false, int STORE = 0>
 __global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I row0, I nrows, I N, const I* __restrict__ rp, const I* __restrict__ ci,
                                                        const T* __restrict__ val, T alpha, const T* __restrict__ x, T beta,
                                                        T* __restrict__ y) {
@@ -40,48 +44,77 @@ __global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I row0, I nrows, I N, co
     const long long gid = blk * BLK + threadIdx.x;
     const int row = row0 + (int)(gid >> 3);
     const int l = threadIdx.x & 7;
-    if (row >= nrows) return;  // whole 8-lane group leaves together
+    const bool active = row < nrows;  // whole 8-lane groups
+    if (STORE != 3 && !active) return;
     const long long N3 = 3LL * N;
     const int r = l >> 1;
     const bool hi = (l & 1);  // false: columns (u0,u1); true: columns (u2,p)
-    const int s = rp[row], e = rp[row + 1];
-    const d2v* __restrict__ v2 = reinterpret_cast<const d2v*>(val) + l;
-    double acc[U];
+    double tot = 0.0;
+    if (active) {
+        const int s = rp[row], e = rp[row + 1];
+        const d2v* __restrict__ v2 = reinterpret_cast<const d2v*>(val) + l;
+        double acc[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) acc[u] = 0.0;
-    int k = s;
-    for (; k + U <= e; k += U) {
-        int c[U];
-        d2v a[U];
-        double xa[U], xb[U];
+        for (int u = 0; u < U; ++u) acc[u] = 0.0;
+        int k = s;
+        for (; k + U <= e; k += U) {
+            int c[U];
+            d2v a[U];
+            double xa[U], xb[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) c[u] = ci[k + u];
+            for (int u = 0; u < U; ++u) c[u] = ci[k + u];
 #pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = ld_val<NT>(v2 + (long long)(k + u) * 8);
+            for (int u = 0; u < U; ++u) a[u] = ld_val<NT>(v2 + (long long)(k + u) * 8);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long long ia = hi ? 3LL * c[u] + 2 : 3LL * c[u];
-            const long long ib = hi ? N3 + c[u] : 3LL * c[u] + 1;
-            xa[u] = x[ia];
-            xb[u] = x[ib];
+            for (int u = 0; u < U; ++u) {
+                const long long ia = hi ? 3LL * c[u] + 2 : 3LL * c[u];
+                const long long ib = hi ? N3 + c[u] : 3LL * c[u] + 1;
+                xa[u] = x[ia];
+                xb[u] = x[ib];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] += a[u].x * xa[u] + a[u].y * xb[u];
         }
+        for (; k < e; ++k) {
+            const int c0 = ci[k];
+            const d2v a0 = ld_val<NT>(v2 + (long long)k * 8);
+            const long long ia = hi ? 3LL * c0 + 2 : 3LL * c0;
+            const long long ib = hi ? N3 + c0 : 3LL * c0 + 1;
+            acc[0] += a0.x * x[ia] + a0.y * x[ib];
+        }
+        tot = acc[0];
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] += a[u].x * xa[u] + a[u].y * xb[u];
+        for (int u = 1; u < U; ++u) tot += acc[u];
     }
-    for (; k < e; ++k) {
-        const int c0 = ci[k];
-        const d2v a0 = ld_val<NT>(v2 + (long long)k * 8);
-        const long long ia = hi ? 3LL * c0 + 2 : 3LL * c0;
-        const long long ib = hi ? N3 + c0 : 3LL * c0 + 1;
-        acc[0] += a0.x * x[ia] + a0.y * x[ib];
-    }
-    double tot = acc[0];
-#pragma unroll
-    for (int u = 1; u < U; ++u) tot += acc[u];
     tot += __shfl_xor(tot, 1, WAVE);
+    if (STORE == 3) {
+        __shared__ double s_y[128];  // [0,96): 32 rows x (u0,u1,u2); [96,128): p of the 32 rows
+        const int lr = threadIdx.x >> 3;
+        if (!hi) s_y[r < 3 ? lr * 3 + r : 96 + lr] = alpha * tot;
+        __syncthreads();
+        const long long R = row0 + blk * (BLK / 8);  // first row of this workgroup
+        const int t = threadIdx.x;
+        if (t < 64) {
+            const bool whole = R + BLK / 8 <= nrows && !((3 * R) & 1) && !((N3 + R) & 1) && !(reinterpret_cast<uintptr_t>(y) & 15);
+            if (whole) {  // one instruction: 8 full 128-byte lines
+                const double2 v = reinterpret_cast<const double2*>(s_y)[t];
+                double2* dst = t < 48 ? reinterpret_cast<double2*>(y + 3 * R) + t : reinterpret_cast<double2*>(y + N3 + R) + (t - 48);
+                *dst = v;
+            } else {
+                for (int i = t; i < 128; i += 64) {
+                    const long long rr = R + (i < 96 ? i / 3 : i - 96);
+                    if (rr < nrows) y[i < 96 ? 3 * R + i : N3 + R + (i - 96)] = s_y[i];
+                }
+            }
+        }
+        return;
+    }
     if (!hi) {
         const long long yi = xidx(row, r, N3);
-        y[yi] = BETA0 ? alpha * tot : alpha * tot + beta * y[yi];
+        const double out = BETA0 ? alpha * tot : alpha * tot + beta * y[yi];
+        if (STORE == 1) { if (out == 1.2345e300) y[yi] = out; }
+        else if (STORE == 2) __builtin_nontemporal_store(out, y + yi);
+        else y[yi] = out;
     }
 }
 
@@ -364,6 +397,9 @@ void dfl_bcsr_spmv_range(I row0, I row1, I N, const I* rp, const I* ci, const T*
             case 1: SPMV_LAUNCH(true, true, 2); break;
             case 2: SPMV_LAUNCH(true, false, 4); break;
             case 3: SPMV_LAUNCH(true, true, 4); break;
+            case 5: bcsr_spmv_kernel<true, true, 4, true, 1><<<grid8, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
+            case 6: bcsr_spmv_kernel<true, true, 4, true, 2><<<grid8, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
+            case 7: bcsr_spmv_kernel<true, true, 4, true, 3><<<grid8, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
             default: bcsr_spmv_kernel<true, true, 4, true><<<grid8, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
         }
     } else {

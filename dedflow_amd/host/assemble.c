@@ -22,10 +22,25 @@ void DflSetRowPatchParameters(index_type leaf_nodes, index_type slot_cap) {
     if (leaf_nodes > 0) g_rowpatch_leaf = leaf_nodes;
     if (slot_cap > 0 && slot_cap <= 1023) g_rowpatch_cap = slot_cap;
 }
+/* slot-owner patches (schedule 4): nodes per patch, cap on their summed row lengths, cap on the tets touching them */
+static index_type g_slotpatch_leaf = 16, g_slotpatch_cap = 255, g_slotpatch_tets = 208;
+void DflSetSlotPatchParameters(index_type leaf_nodes, index_type slot_cap, index_type tet_cap) {
+    if (leaf_nodes > 0) g_slotpatch_leaf = leaf_nodes;
+    if (slot_cap > 0) g_slotpatch_cap = slot_cap;
+    if (tet_cap > 0 && (int64_t)tet_cap * dfl_lhs_slot_record_bytes() <= 160 * 1024) g_slotpatch_tets = tet_cap;
+}
 static index_type g_rhspatch_leaf = 64, g_rhspatch_nodes = 64;
 void DflSetRhsPatchParameters(index_type leaf_tets, index_type node_cap) {
     if (leaf_tets > 0 && leaf_tets <= dfl_rhs_patch_max_tets()) g_rhspatch_leaf = leaf_tets;
     if (node_cap >= 4 && node_cap <= dfl_rhs_patch_max_nodes()) g_rhspatch_nodes = node_cap;
+}
+/* schedule 4: one wave per residual patch; supported shapes (tets, nodes): (16,32), (32,48), (64,64) */
+static index_type g_rhswave_tets = 32, g_rhswave_nodes = 48;
+void DflSetRhsWaveParameters(index_type tets, index_type nodes) {
+    if ((tets == 16 && nodes == 32) || (tets == 32 && nodes == 48) || (tets == 64 && nodes == 64)) {
+        g_rhswave_tets = tets;
+        g_rhswave_nodes = nodes;
+    }
 }
 /* boundary group whose faces carry the weak-BC terms (the reference hard-codes group 4) */
 static index_type g_face_group = 4;
@@ -86,8 +101,9 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
     dfl_pack_nodes(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, x->nodep, s);
     const b32 patch_lhs = J && DflAssemblyScheduleMode() == 2;
     const b32 rowpatch_lhs = J && DflAssemblyScheduleMode() == 3;
+    const b32 slot_lhs = J && DflAssemblyScheduleMode() == 4;
     const b32 patch_rhs = F && DflAssemblyScheduleMode() >= 2;
-    if (J && !x->egeo_b) { /* geometry cache in schedule order (static mesh), built once; the LHS kernels read it */
+    if (J && !slot_lhs && !x->egeo_b) { /* geometry cache in schedule order (static mesh), built once; the LHS kernels read it */
         x->egeo_b = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
         dfl_elem_geometry(mesh->num_tet, x->ien_b, dev->xg, x->egeo_b, s);
     }
@@ -99,7 +115,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
         if (bsz == 0) continue;
         const index_type* ien_b = x->ien_b + (size_t)off * 4;
         if (F && !patch_rhs) DFL_TIMED(DFL_TAG_ASM_RHS, dfl_assemble_tet_rhs(bsz, ien_b, x->nodep, x->Fp, s));
-        if (J && !patch_lhs && !rowpatch_lhs)
+        if (J && !patch_lhs && !rowpatch_lhs && !slot_lhs)
             DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs(bsz, ien_b, x->nzmap_b + (size_t)off * 16, x->egeo_b + (size_t)off * 16,
                                                             x->nodep, val, s));
     }
@@ -134,12 +150,33 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
                                                                  rs->d_slot_nz, x->ien_b, x->egeo_b, x->nodep, val, beta_J,
                                                                  rs->max_slots, s));
     }
-    if (patch_rhs) { /* schedules 2, 3: patch-staged residual, two launches, fixed summation order (host/patch.c) */
-        if (!x->rhspatch) x->rhspatch = DflBuildRhsPatchSchedule(mesh, g_rhspatch_leaf, g_rhspatch_nodes);
+    if (slot_lhs) { /* schedule 4: ONE launch, every nodal nonzero is summed in registers by its owner lanes (host/slotpatch.c) */
+        if (x->slotpatch && x->slotpatch->attr != spy) {
+            DflFreeSlotPatchSchedule(x->slotpatch);
+            x->slotpatch = NULL;
+        }
+        if (!x->slotpatch) x->slotpatch = DflBuildSlotPatchSchedule(mesh, spy, g_slotpatch_leaf, g_slotpatch_cap, g_slotpatch_tets);
+        const SlotPatchSched* ss = x->slotpatch;
+        DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_slot(ss->num_patch, ss->d_hdr, ss->d_ptet_ien, ss->d_slot_nz, ss->d_coff,
+                                                             ss->d_desc, x->nodep, val, beta_J, ss->max_tets, ss->max_slots, ss->max_contrib, s));
+    }
+    if (patch_rhs) { /* schedules 2, 3, 4: patch-staged residual, two launches, fixed summation order (host/patch.c) */
+        const b32 wave = DflAssemblyScheduleMode() >= 4; /* schedule 4: one wave per patch, padded layout */
+        if (x->rhspatch && (x->rhspatch->pad_tets > 0) != wave) {
+            DflFreeRhsPatchSchedule(x->rhspatch);
+            x->rhspatch = NULL;
+        }
+        if (!x->rhspatch)
+            x->rhspatch = wave ? DflBuildRhsPatchSchedule(mesh, g_rhswave_tets, g_rhswave_nodes, g_rhswave_tets, g_rhswave_nodes)
+                               : DflBuildRhsPatchSchedule(mesh, g_rhspatch_leaf, g_rhspatch_nodes, 0, 0);
         const RhsPatchSched* rp = x->rhspatch;
         int slot = DflProfileBegin(DFL_TAG_ASM_RHS);
-        dfl_assemble_tet_rhs_patch(rp->num_patch, rp->d_eoff, rp->d_noff, rp->d_pnode, rp->d_lien, rp->d_adj, rp->d_adj_start,
-                                   x->nodep, rp->d_partial, s);
+        if (wave)
+            dfl_assemble_tet_rhs_wave(rp->num_patch, rp->pad_tets, rp->pad_nodes, rp->d_cnt, rp->d_pnode, rp->d_lien, rp->d_adj,
+                                      rp->d_adj_start, x->nodep, rp->d_partial, s);
+        else
+            dfl_assemble_tet_rhs_patch(rp->num_patch, rp->d_eoff, rp->d_noff, rp->d_pnode, rp->d_lien, rp->d_adj, rp->d_adj_start,
+                                       x->nodep, rp->d_partial, s);
         dfl_rhs_node_sum(N, rp->d_goff, rp->d_gidx, rp->d_partial, F, s);
         DflProfileEnd(slot);
     } else if (F) {
@@ -175,7 +212,7 @@ void AssembleSystem(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J
     hipStream_t s = DflStream();
     if (F) HIPGUARD(hipMemsetAsync(F, 0, (size_t)num_node * sizeof(f64) * BS, s));
     /* schedule 3 writes every row of J exactly once: the zero pass folds into that write */
-    const b32 overwrite = J && DflAssemblyScheduleMode() == 3 && Mesh3DNumTet(mesh) && MatrixFSBlockValues(J);
+    const b32 overwrite = J && DflAssemblyScheduleMode() >= 3 && Mesh3DNumTet(mesh) && MatrixFSBlockValues(J);
     if (J && !overwrite) MatrixZero(J);
     if (Mesh3DNumTet(mesh)) {
         DflAssembleSystemTetBeta(mesh, wgalpha, dwgalpha, F, J, overwrite ? 0.0 : 1.0);

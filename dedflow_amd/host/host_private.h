@@ -33,8 +33,10 @@ typedef struct RhsPatchSched {
     index_type* d_goff;      /* device [N+1] node -> range of gidx */
     index_type* d_gidx;      /* device [total_nodes] partial record ids of each node, ascending patch */
     f64* d_partial;          /* device [total_nodes][6] */
+    index_type pad_tets, pad_nodes; /* > 0: fixed-stride layout (patch p at tet slot p*pad_tets, node slot p*pad_nodes) */
+    index_type* d_cnt;       /* device [P] num_tets | num_nodes << 16 */
 } RhsPatchSched;
-RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_type node_cap);
+RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_type node_cap, index_type pad_tets, index_type pad_nodes);
 void DflFreeRhsPatchSchedule(RhsPatchSched* ps);
 
 /* Row-owner patch schedule (host/rowpatch.c): spatial patches of nodes, each owning its CSR rows. */
@@ -49,6 +51,20 @@ typedef struct RowPatchSched {
 } RowPatchSched;
 RowPatchSched* DflBuildRowPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap);
 void DflFreeRowPatchSchedule(RowPatchSched* ps);
+
+/* Slot-owner patch schedule (host/slotpatch.c): node patches; every nodal nonzero is summed by one lane quad. */
+typedef struct SlotPatchSched {
+    const CSRAttr* attr;
+    index_type num_patch, max_tets, max_slots, max_contrib;
+    int64_t total_tets;
+    int32_t* d_hdr;          /* device [num_patch][8]: tet_off, num_tet, slot_off, num_slot, contrib_off, num_contrib, 0, 0 */
+    index_type* d_ptet_ien;  /* device [total_tets][4] node ids of every (patch, tet) pair */
+    index_type* d_slot_nz;   /* device [nnz1] nodal nonzero of each slot */
+    index_type* d_coff;      /* device [nnz1+1] contribution offsets, slot order */
+    uint16_t* d_desc;        /* device [16T] (local tet << 4) | (a << 2) | b */
+} SlotPatchSched;
+SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap, index_type tet_cap);
+void DflFreeSlotPatchSchedule(SlotPatchSched* ps);
 
 typedef struct MeshExt {
     index_type* ien_b;             /* device [T][4], elements in execution-schedule order */
@@ -72,6 +88,7 @@ typedef struct MeshExt {
     RhsPatchSched* rhspatch;       /* RHS patch schedule (modes 2, 3), built on first use */
     RowPatchSched* rowpatch;       /* LHS row-owner patch schedule (mode 3), built on first use */
     PatchSched* patch;             /* LHS patch schedule (assembly schedule mode 2), built on first use */
+    SlotPatchSched* slotpatch;     /* LHS slot-owner schedule (mode 4, default), built on first use */
 } MeshExt;
 
 void DflMeshPrepareFaces(Mesh3D* mesh, index_type group);

@@ -93,6 +93,7 @@ void Mesh3DDestroy(Mesh3D* m) {
         CdamFreeDevice(x->nzmap_b, 0);
         DflFreePatchSchedule(x->patch);
         DflFreeRowPatchSchedule(x->rowpatch);
+        DflFreeSlotPatchSchedule(x->slotpatch);
         DflFreeRhsPatchSchedule(x->rhspatch);
         CdamFreeDevice(x->egeo_b, 0);
         if (x->h_sched_elem) CdamFreeHost(x->h_sched_elem, 0);

@@ -319,11 +319,17 @@ void DflFreePatchSchedule(PatchSched* ps) {
  * (per-patch adjacency lists) and write one partial record per patch node; a second kernel adds,
  * again in fixed order, the partials of every node into F.  No colors, no atomics, two launches,
  * bitwise reproducible. */
-RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_type node_cap) {
+/* pad_tets / pad_nodes > 0: fixed-stride ("padded") layout for the wave-per-patch kernel -- patch p owns tet slots
+ * [p*pad_tets, (p+1)*pad_tets) and node slots [p*pad_nodes, (p+1)*pad_nodes) (unused node slots hold -1), so every index
+ * array of a patch is addressed from the patch id alone and the loads of a patch form a two-hop chain
+ * (lists -> node records) instead of three (offsets -> lists -> records); d_cnt[p] = num_tets | num_nodes << 16. */
+RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_type node_cap, index_type pad_tets, index_type pad_nodes) {
     const index_type T = mesh->num_tet, N = mesh->num_node;
     const index_type* ien = mesh->host->ien;
     const f64* xg = mesh->host->xg;
     ASSERT(leaf >= 1 && leaf <= dfl_rhs_patch_max_tets() && node_cap >= 4 && node_cap <= dfl_rhs_patch_max_nodes());
+    const int padded = pad_tets > 0 && pad_nodes > 0;
+    ASSERT(!padded || (leaf <= pad_tets && node_cap <= pad_nodes));
     RhsPatchSched* ps = (RhsPatchSched*)CdamMallocHost(SIZE_OF(RhsPatchSched));
     memset(ps, 0, sizeof *ps);
     f64* c = (f64*)malloc(sizeof(f64) * (size_t)T * 3);
@@ -366,19 +372,23 @@ RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_typ
     eoff[0] = noff[0] = 0;
     int64_t totn = 0;
     for (index_type p = 0; p < P; ++p) {
-        eoff[p + 1] = eoff[p] + (x.out[p].hi - x.out[p].lo);
-        totn += nn_of[p];
-        ASSERT(totn < 2147483647LL);
+        eoff[p + 1] = padded ? (p + 1) * pad_tets : eoff[p] + (x.out[p].hi - x.out[p].lo);
+        totn += padded ? pad_nodes : nn_of[p];
+        ASSERT(totn < 2147483647LL && (int64_t)eoff[p + 1] * 4 < 2147483647LL);
         noff[p + 1] = (index_type)totn;
     }
+    const size_t tslots = padded ? (size_t)P * (size_t)pad_tets : (size_t)T;
     index_type* pnode = (index_type*)malloc(sizeof(index_type) * (size_t)(totn > 0 ? totn : 1));
-    u8* lien = (u8*)malloc((size_t)T * 4);
-    uint16_t* adj = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)T * 4);
-    uint16_t* adj_start = (uint16_t*)malloc(sizeof(uint16_t) * ((size_t)totn + (size_t)P));
+    memset(pnode, 0xff, sizeof(index_type) * (size_t)(totn > 0 ? totn : 1)); /* -1 = unused slot (padded layout) */
+    u8* lien = (u8*)calloc(tslots * 4 + 4, 1);
+    uint16_t* adj = (uint16_t*)calloc(tslots * 4 + 4, sizeof(uint16_t));
+    uint16_t* adj_start = (uint16_t*)calloc((size_t)totn + (size_t)P + 1, sizeof(uint16_t));
+    index_type* cnt_of = (index_type*)malloc(sizeof(index_type) * (size_t)(P > 0 ? P : 1));
 #pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
     for (index_type p = 0; p < P; ++p) {
         const index_type lo = x.out[p].lo, ne = x.out[p].hi - lo, nn = nn_of[p];
         const index_type* keys = nodes_of[p];
+        cnt_of[p] = ne | (nn << 16);
         memcpy(pnode + noff[p], keys, sizeof(index_type) * (size_t)nn);
         uint16_t cnt[256]; /* node_cap <= 255: local node ids are bytes */
         memset(cnt, 0, sizeof cnt);
@@ -407,13 +417,13 @@ RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_typ
     }
     /* node -> its partial records (ascending patch order) */
     index_type* goff = (index_type*)calloc((size_t)N + 1, sizeof(index_type));
-    for (int64_t i = 0; i < totn; ++i) goff[pnode[i] + 1]++;
+    for (int64_t i = 0; i < totn; ++i) if (pnode[i] >= 0) goff[pnode[i] + 1]++;
     for (index_type n = 0; n < N; ++n) goff[n + 1] += goff[n];
     index_type* gidx = (index_type*)malloc(sizeof(index_type) * (size_t)(totn > 0 ? totn : 1));
     {
         index_type* cur = (index_type*)malloc(sizeof(index_type) * (size_t)N);
         memcpy(cur, goff, sizeof(index_type) * (size_t)N);
-        for (int64_t i = 0; i < totn; ++i) gidx[cur[pnode[i]]++] = (index_type)i;
+        for (int64_t i = 0; i < totn; ++i) if (pnode[i] >= 0) gidx[cur[pnode[i]]++] = (index_type)i;
         free(cur);
     }
     ps->num_patch = P;
@@ -421,8 +431,12 @@ RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_typ
     ps->d_eoff = (index_type*)CdamMallocDevice(((ptrdiff_t)P + 1) * SIZE_OF(index_type));
     ps->d_noff = (index_type*)CdamMallocDevice(((ptrdiff_t)P + 1) * SIZE_OF(index_type));
     ps->d_pnode = (index_type*)CdamMallocDevice((ptrdiff_t)(totn > 0 ? totn : 1) * SIZE_OF(index_type));
-    ps->d_lien = (u8*)CdamMallocDevice((ptrdiff_t)T * 4);
-    ps->d_adj = (uint16_t*)CdamMallocDevice((ptrdiff_t)T * 4 * (ptrdiff_t)sizeof(uint16_t));
+    ps->pad_tets = padded ? pad_tets : 0;
+    ps->pad_nodes = padded ? pad_nodes : 0;
+    ps->d_cnt = (index_type*)CdamMallocDevice((ptrdiff_t)(P > 0 ? P : 1) * SIZE_OF(index_type));
+    HIPGUARD(hipMemcpy(ps->d_cnt, cnt_of, sizeof(index_type) * (size_t)P, H2D));
+    ps->d_lien = (u8*)CdamMallocDevice((ptrdiff_t)tslots * 4 + 4);
+    ps->d_adj = (uint16_t*)CdamMallocDevice(((ptrdiff_t)tslots * 4 + 4) * (ptrdiff_t)sizeof(uint16_t));
     ps->d_adj_start = (uint16_t*)CdamMallocDevice(((ptrdiff_t)totn + P) * (ptrdiff_t)sizeof(uint16_t));
     ps->d_goff = (index_type*)CdamMallocDevice(((ptrdiff_t)N + 1) * SIZE_OF(index_type));
     ps->d_gidx = (index_type*)CdamMallocDevice((ptrdiff_t)(totn > 0 ? totn : 1) * SIZE_OF(index_type));
@@ -430,14 +444,15 @@ RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_typ
     HIPGUARD(hipMemcpy(ps->d_eoff, eoff, sizeof(index_type) * ((size_t)P + 1), H2D));
     HIPGUARD(hipMemcpy(ps->d_noff, noff, sizeof(index_type) * ((size_t)P + 1), H2D));
     HIPGUARD(hipMemcpy(ps->d_pnode, pnode, sizeof(index_type) * (size_t)totn, H2D));
-    HIPGUARD(hipMemcpy(ps->d_lien, lien, (size_t)T * 4, H2D));
-    HIPGUARD(hipMemcpy(ps->d_adj, adj, sizeof(uint16_t) * (size_t)T * 4, H2D));
+    HIPGUARD(hipMemcpy(ps->d_lien, lien, tslots * 4, H2D));
+    HIPGUARD(hipMemcpy(ps->d_adj, adj, sizeof(uint16_t) * tslots * 4, H2D));
     HIPGUARD(hipMemcpy(ps->d_adj_start, adj_start, sizeof(uint16_t) * ((size_t)totn + (size_t)P), H2D));
     HIPGUARD(hipMemcpy(ps->d_goff, goff, sizeof(index_type) * ((size_t)N + 1), H2D));
     HIPGUARD(hipMemcpy(ps->d_gidx, gidx, sizeof(index_type) * (size_t)totn, H2D));
     if (verbose) fprintf(stderr, "[rhspatch] %d patches, %lld patch nodes (%.2f per node) in %.2f s\n", P, (long long)totn,
                          (double)totn / (double)(N > 0 ? N : 1), omp_get_wtime() - t0);
     for (index_type p = 0; p < P; ++p) free(nodes_of[p]);
+    free(cnt_of);
     free(gidx); free(goff); free(adj_start); free(adj); free(lien); free(pnode);
     free(nodes_of); free(nn_of); free(noff); free(eoff); free(x.out); free(idx); free(c);
     return ps;
@@ -447,7 +462,7 @@ void DflFreeRhsPatchSchedule(RhsPatchSched* ps) {
     if (!ps) return;
     CdamFreeDevice(ps->d_eoff, 0); CdamFreeDevice(ps->d_noff, 0); CdamFreeDevice(ps->d_pnode, 0);
     CdamFreeDevice(ps->d_lien, 0); CdamFreeDevice(ps->d_adj, 0); CdamFreeDevice(ps->d_adj_start, 0);
-    CdamFreeDevice(ps->d_goff, 0); CdamFreeDevice(ps->d_gidx, 0);
+    CdamFreeDevice(ps->d_goff, 0); CdamFreeDevice(ps->d_gidx, 0); CdamFreeDevice(ps->d_cnt, 0);
     CdamFreeDevice(ps->d_partial, 0);
     CdamFreeHost(ps, SIZE_OF(RhsPatchSched));
 }

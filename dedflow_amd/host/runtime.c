@@ -217,6 +217,9 @@ static void device_free(void* ptr, ptrdiff_t size, UserCtxPtr ctx) {
 static Allocator g_alloc[2] = {{host_malloc, host_free, NULL}, {device_malloc, device_free, NULL}};
 
 Allocator* GetDefaultAllocator(int device_id) { return &g_alloc[device_id == DEVICE ? 1 : 0]; }
+/* the CdamMallocDevice / CdamFreeDevice macros as functions (bindings that cannot expand C macros) */
+void* DflDeviceMalloc(int64_t bytes) { return CdamMallocDevice((ptrdiff_t)bytes); }
+void DflDeviceFree(void* ptr) { CdamFreeDevice(ptr, 0); }
 
 /* ---- vec.h ------------------------------------------------------------------ */
 void VecAXPY(value_type a, const value_type* x, value_type* y, index_type n) { dfl_daxpy(n, a, x, y, g_stream); }

@@ -1,0 +1,342 @@
+/* Slot-owner patch schedule for the Jacobian assembly (assembly schedule mode 4, default).
+ *
+ * The colored scatter of the reference (src/assemble.cu:1362-1371 -> src/matrix_impl.cu:370-453) read-modify-writes
+ * a 128-byte block line once per contributing tet.  Here the NODES are clustered into spatial patches (recursive
+ * coordinate bisection) and one workgroup owns every CSR row of its nodes -- like schedule 3 -- but the sum of a
+ * nodal nonzero ("slot") is formed in REGISTERS by the lane group that owns the slot:
+ *   phase 1  one lane per tet touching the patch: geometry, convective shape derivatives and stabilisation
+ *            parameters at the 4 quadrature points -> a 304-byte record in LDS;
+ *   phase 2  one lane quad per slot walks the slot's list of (tet, a, b) contributions (this file builds it),
+ *            evaluates the (a, b) block of each from the LDS records, adds them in list order and writes the
+ *            128-byte line once.
+ * No LDS or HBM atomics, one launch, fixed summation order (bitwise reproducible), no per-element geometry cache
+ * (geometry is recomputed from the node records, so moving meshes need no invalidation).
+ *
+ * Layout produced here (all device arrays):
+ *   hdr[p]      = {tet_off, num_tet, slot_off, num_slot, contrib_off, num_contrib, 0, 0}
+ *   ptet_ien    [sum num_tet][4]  node ids of every (patch, tet) pair, ascending element id inside a patch
+ *   slot_nz     [nnz1]            nodal nonzero of every slot; inside a patch the slots are sorted by contribution
+ *                                 count (descending) and dealt to the four waves in snake order, so that the 16 lane
+ *                                 quads of a wave see equal trip counts
+ *   coff        [nnz1 + 1]        contribution offsets in slot order
+ *   desc        [16 T]            (local tet << 4) | (a << 2) | b, ascending local tet inside a slot
+ */
+#include <string.h>
+#include <omp.h>
+#include "dedflow.h"
+#include "dedflow_kernels.h"
+#include "host_private.h"
+
+typedef struct { index_type lo, hi; } Range;
+typedef struct {
+    const f64* c;          /* node coordinates */
+    index_type* idx;       /* node permutation (RCB order) */
+    const index_type* rp;  /* host nodal row pointer */
+    const index_type* vp;  /* node -> tet list offsets */
+    const index_type* ve;  /* tet*4 + a, ascending tet inside a node */
+    index_type leaf, cap, tcap;
+    Range* out;
+    index_type nout, capout;
+} Ctx;
+
+static int key_less(const f64* c, int ax, index_type a, index_type b) {
+    f64 va = c[(size_t)a * 3 + ax], vb = c[(size_t)b * 3 + ax];
+    return va < vb || (va == vb && a < b);
+}
+static void select_kth(const f64* c, int ax, index_type* idx, index_type n, index_type k) {
+    index_type lo = 0, hi = n - 1;
+    while (lo < hi) {
+        index_type p = idx[lo + (hi - lo) / 2], i = lo, j = hi;
+        while (i <= j) {
+            while (key_less(c, ax, idx[i], p)) ++i;
+            while (key_less(c, ax, p, idx[j])) --j;
+            if (i <= j) { index_type t = idx[i]; idx[i] = idx[j]; idx[j] = t; ++i; --j; }
+        }
+        if (k <= j) hi = j; else if (k >= i) lo = i; else return;
+    }
+}
+static int cmp_i32(const void* a, const void* b) {
+    index_type x = *(const index_type*)a, y = *(const index_type*)b;
+    return (x > y) - (x < y);
+}
+static int cmp_range(const void* a, const void* b) {
+    index_type x = ((const Range*)a)->lo, y = ((const Range*)b)->lo;
+    return (x > y) - (x < y);
+}
+static void emit(Ctx* x, index_type lo, index_type hi) {
+#pragma omp critical(dfl_slotpatch_emit)
+    {
+        if (x->nout == x->capout) {
+            x->capout *= 2;
+            x->out = (Range*)realloc(x->out, sizeof(Range) * (size_t)x->capout);
+        }
+        x->out[x->nout].lo = lo;
+        x->out[x->nout].hi = hi;
+        x->nout++;
+    }
+}
+/* distinct tets touching the nodes idx[lo..hi) */
+static index_type count_tets(const Ctx* x, index_type lo, index_type hi) {
+    index_type tmp[4096];
+    index_type m = 0;
+    for (index_type i = lo; i < hi; ++i) {
+        const index_type n = x->idx[i];
+        for (index_type j = x->vp[n]; j < x->vp[n + 1]; ++j) {
+            if (m == 4096) return 4096;
+            tmp[m++] = x->ve[j] >> 2;
+        }
+    }
+    qsort(tmp, (size_t)m, sizeof(index_type), cmp_i32);
+    index_type u = 0;
+    for (index_type i = 0; i < m; ++i)
+        if (i == 0 || tmp[i] != tmp[i - 1]) ++u;
+    return u;
+}
+static void split(Ctx* x, index_type lo, index_type hi) {
+    const index_type n = hi - lo;
+    if (n <= x->leaf) {
+        int64_t slots = 0;
+        for (index_type i = lo; i < hi; ++i) slots += x->rp[x->idx[i] + 1] - x->rp[x->idx[i]];
+        if (n <= 1 || (slots <= x->cap && count_tets(x, lo, hi) <= x->tcap)) { emit(x, lo, hi); return; }
+    }
+    f64 bl[3] = {1e300, 1e300, 1e300}, bh[3] = {-1e300, -1e300, -1e300};
+    for (index_type i = lo; i < hi; ++i)
+        for (int d = 0; d < 3; ++d) {
+            f64 v = x->c[(size_t)x->idx[i] * 3 + d];
+            if (v < bl[d]) bl[d] = v;
+            if (v > bh[d]) bh[d] = v;
+        }
+    int ax = 0;
+    if (bh[1] - bl[1] > bh[ax] - bl[ax]) ax = 1;
+    if (bh[2] - bl[2] > bh[ax] - bl[ax]) ax = 2;
+    const index_type half = n / 2;
+    select_kth(x->c, ax, x->idx + lo, n, half);
+    if (n > 4096) {
+#pragma omp task
+        split(x, lo, lo + half);
+#pragma omp task
+        split(x, lo + half, hi);
+#pragma omp taskwait
+    } else {
+        split(x, lo, lo + half);
+        split(x, lo + half, hi);
+    }
+}
+static index_type find_nz(const index_type* rp, const index_type* ci, index_type row, index_type col) {
+    index_type lo = rp[row], hi = rp[row + 1] - 1;
+    while (lo < hi) {
+        index_type mid = (lo + hi) >> 1;
+        if (ci[mid] < col) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap, index_type tet_cap) {
+    const index_type T = mesh->num_tet, N = mesh->num_node;
+    const index_type* ien = mesh->host->ien;
+    const f64* xg = mesh->host->xg;
+    ASSERT((int64_t)T * 16 < 2147483647LL && "slot-patch contribution offsets are 32-bit");
+    if (tet_cap > 4095) tet_cap = 4095; /* 12-bit local tet ids in the descriptors */
+    SlotPatchSched* ps = (SlotPatchSched*)CdamMallocHost(SIZE_OF(SlotPatchSched));
+    memset(ps, 0, sizeof *ps);
+    ps->attr = spy;
+    index_type* rp = (index_type*)malloc(sizeof(index_type) * ((size_t)N + 1));
+    index_type* ci = (index_type*)malloc(sizeof(index_type) * (size_t)spy->nnz);
+    HIPGUARD(hipMemcpy(rp, spy->row_ptr, sizeof(index_type) * ((size_t)N + 1), D2H));
+    HIPGUARD(hipMemcpy(ci, spy->col_ind, sizeof(index_type) * (size_t)spy->nnz, D2H));
+    int nt = omp_get_max_threads();
+    if (getenv("DFL_HOST_THREADS")) nt = atoi(getenv("DFL_HOST_THREADS"));
+    if (nt > 16) nt = 16; /* a GPU box grants one rank a ~16-core share of a much wider host */
+    if (nt < 1) nt = 1;
+    const int verbose = getenv("DFL_PATCH_VERBOSE") != NULL;
+    double t0 = omp_get_wtime();
+
+    /* node -> (tet, a) lists, ascending tet inside a node */
+    index_type* vp = (index_type*)calloc((size_t)N + 1, sizeof(index_type));
+    for (size_t i = 0; i < (size_t)T * 4; ++i) vp[ien[i] + 1]++;
+    for (index_type n = 0; n < N; ++n) vp[n + 1] += vp[n];
+    index_type* ve = (index_type*)malloc(sizeof(index_type) * (size_t)T * 4);
+    {
+        index_type* cur = (index_type*)malloc(sizeof(index_type) * (size_t)N);
+        memcpy(cur, vp, sizeof(index_type) * (size_t)N);
+        for (index_type e = 0; e < T; ++e)
+            for (int a = 0; a < 4; ++a) ve[cur[ien[(size_t)e * 4 + a]]++] = e * 4 + a;
+        free(cur);
+    }
+    index_type* idx = (index_type*)malloc(sizeof(index_type) * (size_t)N);
+    for (index_type n = 0; n < N; ++n) idx[n] = n;
+    Ctx x = {xg, idx, rp, vp, ve, leaf, slot_cap, tet_cap, NULL, 0, 1024};
+    x.out = (Range*)malloc(sizeof(Range) * (size_t)x.capout);
+#pragma omp parallel num_threads(nt)
+#pragma omp single
+    split(&x, 0, N);
+    qsort(x.out, (size_t)x.nout, sizeof(Range), cmp_range);
+    const index_type P = x.nout;
+
+    /* pass 1: per-patch tet lists and sizes */
+    index_type** tets_of = (index_type**)malloc(sizeof(index_type*) * (size_t)P);
+    index_type* nt_of = (index_type*)malloc(sizeof(index_type) * (size_t)P);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+    for (index_type p = 0; p < P; ++p) {
+        const index_type lo = x.out[p].lo, nn = x.out[p].hi - lo;
+        index_type* nodes = idx + lo;
+        qsort(nodes, (size_t)nn, sizeof(index_type), cmp_i32); /* rows of a patch in ascending node order */
+        index_type m = 0;
+        for (index_type k = 0; k < nn; ++k) m += vp[nodes[k] + 1] - vp[nodes[k]];
+        index_type* tl = (index_type*)malloc(sizeof(index_type) * (size_t)(m > 0 ? m : 1));
+        m = 0;
+        for (index_type k = 0; k < nn; ++k)
+            for (index_type j = vp[nodes[k]]; j < vp[nodes[k] + 1]; ++j) tl[m++] = ve[j] >> 2;
+        qsort(tl, (size_t)m, sizeof(index_type), cmp_i32);
+        index_type u = 0;
+        for (index_type i = 0; i < m; ++i)
+            if (i == 0 || tl[i] != tl[i - 1]) tl[u++] = tl[i];
+        tets_of[p] = tl;
+        nt_of[p] = u;
+    }
+    int32_t* hdr = (int32_t*)calloc((size_t)P * 8 + 8, sizeof(int32_t));
+    int64_t tot_t = 0, tot_s = 0;
+    index_type maxt = 0, maxs = 0;
+    for (index_type p = 0; p < P; ++p) {
+        int64_t ns = 0;
+        for (index_type i = x.out[p].lo; i < x.out[p].hi; ++i) ns += rp[idx[i] + 1] - rp[idx[i]];
+        ASSERT(nt_of[p] <= 4095 && "slot-patch descriptors hold 12-bit local tet ids");
+        hdr[8 * p + 0] = (int32_t)tot_t;
+        hdr[8 * p + 1] = nt_of[p];
+        hdr[8 * p + 2] = (int32_t)tot_s;
+        hdr[8 * p + 3] = (int32_t)ns;
+        tot_t += nt_of[p];
+        tot_s += ns;
+        ASSERT(tot_t < 2147483647LL);
+        if (nt_of[p] > maxt) maxt = nt_of[p];
+        if (ns > maxs) maxs = (index_type)ns;
+    }
+    ASSERT(tot_s == spy->nnz);
+    if (verbose)
+        fprintf(stderr, "[slotpatch] %d patches (<= %d nodes / %d slots / %d tets): %.2f tets per patch-tet list entry per tet, max tets %d, "
+                        "max slots %d, %.2f s\n", P, leaf, slot_cap, tet_cap, (double)tot_t / (double)(T > 0 ? T : 1), maxt, maxs, omp_get_wtime() - t0);
+
+    index_type* ptet_ien = (index_type*)malloc(sizeof(index_type) * 4 * (size_t)(tot_t > 0 ? tot_t : 1));
+    index_type* slot_nz = (index_type*)malloc(sizeof(index_type) * (size_t)spy->nnz);
+    index_type* coff = (index_type*)malloc(sizeof(index_type) * ((size_t)spy->nnz + 1));
+    uint16_t* desc = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)T * 16);
+    /* contribution counts per patch first (prefix over patches), then the fill */
+    int64_t* cbase = (int64_t*)malloc(sizeof(int64_t) * ((size_t)P + 1));
+    index_type maxc_all = 0;
+    cbase[0] = 0;
+    for (index_type p = 0; p < P; ++p) {
+        int64_t items = 0;
+        for (index_type i = x.out[p].lo; i < x.out[p].hi; ++i) items += vp[idx[i] + 1] - vp[idx[i]];
+        cbase[p + 1] = cbase[p] + items * 4;
+        hdr[8 * p + 4] = (int32_t)cbase[p];
+        hdr[8 * p + 5] = (int32_t)(items * 4);
+        if (items * 4 > maxc_all) maxc_all = (index_type)(items * 4);
+    }
+    ASSERT(cbase[P] == (int64_t)T * 16);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+    for (index_type p = 0; p < P; ++p) {
+        const index_type lo = x.out[p].lo, nn = x.out[p].hi - lo;
+        const index_type* nodes = idx + lo;
+        const index_type ntp = nt_of[p], ns = hdr[8 * p + 3], s0 = hdr[8 * p + 2];
+        const index_type* tl = tets_of[p];
+        for (index_type k = 0; k < ntp; ++k) memcpy(ptet_ien + ((size_t)hdr[8 * p] + k) * 4, ien + (size_t)tl[k] * 4, 4 * sizeof(index_type));
+        index_type* rowbase = (index_type*)malloc(sizeof(index_type) * (size_t)nn);
+        index_type* cnt = (index_type*)calloc((size_t)ns, sizeof(index_type));
+        index_type sb = 0;
+        for (index_type k = 0; k < nn; ++k) { rowbase[k] = sb; sb += rp[nodes[k] + 1] - rp[nodes[k]]; }
+        /* items of the patch in ascending (tet, a) order: merge of the per-node lists */
+        index_type ni = (index_type)((cbase[p + 1] - cbase[p]) / 4);
+        int64_t* it = (int64_t*)malloc(sizeof(int64_t) * (size_t)(ni > 0 ? ni : 1)); /* (ea << 16) | k */
+        index_type m = 0;
+        for (index_type k = 0; k < nn; ++k)
+            for (index_type j = vp[nodes[k]]; j < vp[nodes[k] + 1]; ++j) it[m++] = ((int64_t)ve[j] << 16) | k;
+        /* int64 keys order by (tet, a) first: shell sort (a few hundred entries) */
+        {
+            for (index_type gap = m / 2; gap > 0; gap /= 2)
+                for (index_type i = gap; i < m; ++i) {
+                    int64_t v = it[i];
+                    index_type j = i;
+                    for (; j >= gap && it[j - gap] > v; j -= gap) it[j] = it[j - gap];
+                    it[j] = v;
+                }
+        }
+        index_type* islot = (index_type*)malloc(sizeof(index_type) * 4 * (size_t)(ni > 0 ? ni : 1));
+        index_type* ilt = (index_type*)malloc(sizeof(index_type) * (size_t)(ni > 0 ? ni : 1));
+        index_type cur_lt = 0;
+        for (index_type i = 0; i < m; ++i) {
+            const index_type ea = (index_type)(it[i] >> 16), k = (index_type)(it[i] & 0xffff);
+            const index_type e = ea >> 2, n = nodes[k];
+            while (tl[cur_lt] < e) ++cur_lt; /* tl ascending, items ascending */
+            ilt[i] = cur_lt;
+            for (int b = 0; b < 4; ++b) {
+                const index_type s = rowbase[k] + find_nz(rp, ci, n, ien[(size_t)e * 4 + b]) - rp[n];
+                islot[4 * i + b] = s;
+                cnt[s]++;
+            }
+        }
+        /* slots sorted by count (descending, stable), dealt to the four waves in snake order (chunks of 16 quads) */
+        index_type maxc = 0;
+        for (index_type s = 0; s < ns; ++s) if (cnt[s] > maxc) maxc = cnt[s];
+        index_type* bucket = (index_type*)calloc((size_t)maxc + 2, sizeof(index_type));
+        for (index_type s = 0; s < ns; ++s) bucket[maxc - cnt[s] + 1]++;
+        for (index_type c = 0; c <= maxc; ++c) bucket[c + 1] += bucket[c];
+        index_type* pos_of = (index_type*)malloc(sizeof(index_type) * (size_t)(ns > 0 ? ns : 1));
+        const index_type full = (ns / 64) * 64;
+        for (index_type s = 0; s < ns; ++s) {
+            const index_type r = bucket[maxc - cnt[s]]++;
+            index_type pos = r;
+            if (r < full) {
+                const index_type chunk = r >> 4, i = r & 15, k = chunk >> 2, w = chunk & 3;
+                pos = k * 64 + ((k & 1) ? 3 - w : w) * 16 + i;
+            }
+            pos_of[s] = pos;
+        }
+        /* offsets in position order */
+        index_type* cpos = (index_type*)malloc(sizeof(index_type) * ((size_t)ns + 1));
+        for (index_type s = 0; s < ns; ++s) cpos[pos_of[s] + 1] = cnt[s];
+        cpos[0] = 0;
+        for (index_type s = 0; s < ns; ++s) cpos[s + 1] += cpos[s];
+        for (index_type s = 0; s < ns; ++s) coff[s0 + s] = (index_type)(cbase[p] + cpos[s]);
+        {
+            index_type sidx = 0;
+            for (index_type k = 0; k < nn; ++k)
+                for (index_type z = rp[nodes[k]]; z < rp[nodes[k] + 1]; ++z) slot_nz[s0 + pos_of[sidx++]] = z;
+        }
+        for (index_type i = 0; i < m; ++i) {
+            const index_type a = (index_type)((it[i] >> 16) & 3);
+            for (int b = 0; b < 4; ++b) {
+                const index_type s = islot[4 * i + b];
+                desc[cbase[p] + cpos[pos_of[s]]++] = (uint16_t)((ilt[i] << 4) | (a << 2) | b);
+            }
+        }
+        free(cpos); free(pos_of); free(bucket); free(ilt); free(islot); free(it); free(cnt); free(rowbase);
+        free(tets_of[p]);
+    }
+    coff[spy->nnz] = (index_type)cbase[P];
+    ps->num_patch = P;
+    ps->max_tets = maxt;
+    ps->max_slots = maxs;
+    ps->max_contrib = maxc_all;
+    ps->total_tets = tot_t;
+    ps->d_hdr = (int32_t*)CdamMallocDevice((ptrdiff_t)P * 8 * (ptrdiff_t)sizeof(int32_t) + 32);
+    ps->d_ptet_ien = (index_type*)CdamMallocDevice((ptrdiff_t)(tot_t > 0 ? tot_t : 1) * 4 * SIZE_OF(index_type));
+    ps->d_slot_nz = (index_type*)CdamMallocDevice((ptrdiff_t)spy->nnz * SIZE_OF(index_type));
+    ps->d_coff = (index_type*)CdamMallocDevice(((ptrdiff_t)spy->nnz + 1) * SIZE_OF(index_type));
+    ps->d_desc = (uint16_t*)CdamMallocDevice((ptrdiff_t)T * 16 * (ptrdiff_t)sizeof(uint16_t));
+    HIPGUARD(hipMemcpy(ps->d_hdr, hdr, sizeof(int32_t) * 8 * (size_t)P, H2D));
+    HIPGUARD(hipMemcpy(ps->d_ptet_ien, ptet_ien, sizeof(index_type) * 4 * (size_t)tot_t, H2D));
+    HIPGUARD(hipMemcpy(ps->d_slot_nz, slot_nz, sizeof(index_type) * (size_t)spy->nnz, H2D));
+    HIPGUARD(hipMemcpy(ps->d_coff, coff, sizeof(index_type) * ((size_t)spy->nnz + 1), H2D));
+    HIPGUARD(hipMemcpy(ps->d_desc, desc, sizeof(uint16_t) * (size_t)T * 16, H2D));
+    if (verbose) fprintf(stderr, "[slotpatch] uploaded at %.2f s\n", omp_get_wtime() - t0);
+    free(cbase); free(desc); free(coff); free(slot_nz); free(ptet_ien); free(hdr); free(nt_of); free(tets_of);
+    free(x.out); free(idx); free(ve); free(vp); free(ci); free(rp);
+    return ps;
+}
+
+void DflFreeSlotPatchSchedule(SlotPatchSched* ps) {
+    if (!ps) return;
+    CdamFreeDevice(ps->d_hdr, 0); CdamFreeDevice(ps->d_ptet_ien, 0); CdamFreeDevice(ps->d_slot_nz, 0);
+    CdamFreeDevice(ps->d_coff, 0); CdamFreeDevice(ps->d_desc, 0);
+    CdamFreeHost(ps, SIZE_OF(SlotPatchSched));
+}

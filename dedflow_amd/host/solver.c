@@ -212,10 +212,11 @@ typedef struct KrylovExt {
     DflComm comm;
     b32 has_comm;
     PCType pc_type; /* tree KrylovSolve builds: PC_DECOMPOSITION (reference) or PC_ILU0 */
+    index_type restart; /* GMRES(m): basis columns per cycle; <= 0 or >= max_iter = full GMRES (the reference, krylov.c:56-334) */
     b32 fused_norm; /* partitioned runs: ||w - Qh|| from w.w - sum h^2, one all-reduce per Arnoldi step (off by default) */
     int* d_flag;    /* device int raised by the fused-norm kernel on heavy cancellation */
     /* cached GMRES work space */
-    index_type ws_n, ws_maxit;
+    index_type ws_n, ws_maxit, ws_hist;
     f64 *Q, *H, *tmp, *gv, *beta, *res_hist, *nrm, *work;
     int64_t work_len;
 } KrylovExt;
@@ -249,6 +250,7 @@ void KrylovSetPCType(Krylov* k, PCType type) {
 }
 PC* KrylovGetPC(const Krylov* k) { return (PC*)k->pc; }
 void KrylovSetFusedNorm(Krylov* k, b32 on) { kext(k)->fused_norm = on; }
+void KrylovSetRestart(Krylov* k, index_type m) { kext(k)->restart = m; }
 const DflComm* KrylovGetComm(const Krylov* k) { return kext(k)->has_comm ? &kext(k)->comm : NULL; }
 void KrylovSetComm(Krylov* k, const DflComm* comm) {
     KrylovExt* x = kext(k);
@@ -262,18 +264,20 @@ static void ws_free(KrylovExt* x) {
     CdamFreeDevice(x->d_flag, 0);
     x->d_flag = NULL;
     x->Q = x->H = x->tmp = x->gv = x->beta = x->res_hist = x->nrm = x->work = NULL;
-    x->ws_n = x->ws_maxit = 0;
+    x->ws_n = x->ws_maxit = x->ws_hist = 0;
 }
 
-static void ws_ensure(KrylovExt* x, index_type n, index_type maxit, index_type ldh) {
-    if (x->ws_n == n && x->ws_maxit == maxit) return;
+/* maxit = basis columns per cycle (the restart length, or max_iter for full GMRES); hist = entries of the residual history */
+static void ws_ensure(KrylovExt* x, index_type n, index_type maxit, index_type ldh, index_type hist) {
+    if (x->ws_n == n && x->ws_maxit == maxit && x->ws_hist >= hist) return;
     ws_free(x);
     x->Q = (f64*)CdamMallocDevice((ptrdiff_t)n * SIZE_OF(f64) * (maxit + 1));
     x->H = (f64*)CdamMallocDevice((ptrdiff_t)ldh * maxit * SIZE_OF(f64));
     x->tmp = (f64*)CdamMallocDevice((ptrdiff_t)n * 2 * SIZE_OF(f64));
     x->gv = (f64*)CdamMallocDevice(2 * (ptrdiff_t)maxit * SIZE_OF(f64));
     x->beta = (f64*)CdamMallocDevice(((ptrdiff_t)maxit + 1) * SIZE_OF(f64));
-    x->res_hist = (f64*)CdamMallocDevice(((ptrdiff_t)maxit + 1) * SIZE_OF(f64));
+    x->res_hist = (f64*)CdamMallocDevice(((ptrdiff_t)hist + 1) * SIZE_OF(f64));
+    x->ws_hist = hist;
     x->nrm = (f64*)CdamMallocDevice(((ptrdiff_t)maxit + 2) * SIZE_OF(f64));
     x->work_len = dfl_cgs_work_size(n, maxit + 1) + dfl_reduce_work_size();
     x->work = (f64*)CdamMallocDevice((ptrdiff_t)x->work_len * SIZE_OF(f64));
@@ -315,23 +319,39 @@ static void pc_apply_fused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64*
     else dfl_dcopy(na, w, z, DflStream());
 }
 
+/* partitioned runs: the local dot products cover ghost rows too, so those must be zero in every Krylov vector (SpMV and
+ * the PC write owned rows only); enforced here for the residual instead of relying on the caller */
+static void zero_ghost_rows(const KrylovExt* ex, Matrix* A, f64* v, index_type na) {
+    if (!ex->has_comm || !MatrixFSBlockValues(A)) return;
+    const index_type N = ((MatrixFS*)A->data)->spy1x1->num_row, no = ex->comm.num_owned_node;
+    hipStream_t s = DflStream();
+    if (no >= N || no < 0) return;
+    HIPGUARD(hipMemsetAsync(v + (size_t)no * 3, 0, (size_t)(N - no) * 3 * sizeof(f64), s));
+    for (index_type sec = 3; sec < 6 && (size_t)(sec + 1) * (size_t)N <= (size_t)na; ++sec)
+        HIPGUARD(hipMemsetAsync(v + (size_t)sec * N + no, 0, (size_t)(N - no) * sizeof(f64), s));
+}
+
 static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     Krylov* ksp = (Krylov*)ctx;
     KrylovExt* ex = kext(ksp);
     PC* pc = (PC*)ksp->pc;
     hipStream_t s = DflStream();
     const index_type maxit = ksp->max_iter;
+    /* GMRES(m): m basis columns per cycle, then x is updated, the true residual recomputed and the recurrence restarted.
+       Not in the reference (its AMGX sketch asks for gmres_n_restart, krylov.c:409-437); m >= max_iter (default) is the
+       reference's full GMRES, bit for bit the same sequence of operations as before */
+    const index_type m = (ex->restart > 0 && ex->restart < maxit) ? ex->restart : maxit;
     const f64 atol = ksp->atol, rtol = ksp->rtol;
     const index_type n = MatrixNumRow(A);
-    const index_type ldh = CEIL_DIV(maxit + 1, 32) * 32;
+    const index_type ldh = CEIL_DIV(m + 1, 32) * 32;
     const b32 dist = ex->has_comm;
     f64 rnrm_init = 0.0, rnrm = 0.0;
     b32 converged = FALSE;
-    index_type iter = 0;
+    index_type total = 0; /* iterations over all cycles */
     const index_type n_interior = dist ? ex->comm.num_interior_node : 0;
     const b32 split_rows = dist && n_interior > 0 && MatrixFSBlockValues(A) && n_interior <= MatrixFSOwnedRows(A);
 
-    ws_ensure(ex, n, maxit, ldh);
+    ws_ensure(ex, n, m, ldh, maxit);
     /* active length: [0,4N) if the matrix is the block-mode (u,p) system and b's tail is zero (Q5) */
     index_type na = n;
     b32 x_is_zero = FALSE;
@@ -347,93 +367,108 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     f64* tmp = ex->tmp;
 #define QCOL(c) (Q + (size_t)(c) * (size_t)na)
 #define HCOL(c) (H + (size_t)(c) * (size_t)ldh)
-    HIPGUARD(hipMemsetAsync(H, 0, (size_t)ldh * maxit * sizeof(f64), s));
-    HIPGUARD(hipMemsetAsync(ex->beta, 0, ((size_t)maxit + 1) * sizeof(f64), s));
-    HIPGUARD(hipMemsetAsync(ex->gv, 0, 2 * (size_t)maxit * sizeof(f64), s));
-
-    /* 0. r = b - A x  (krylov.c:112-116) */
-    dfl_dcopy(na, b, QCOL(0), s);
-    if (dist) ex->comm.halo_exchange(ex->comm.ctx, x);
-    if (!x_is_zero) MatrixAMVPBY(A, -1.0, x, 1.0, QCOL(0));
-    if (dist) {
-        dfl_ddot(na, QCOL(0), QCOL(0), ex->nrm, ex->work, s);
-        ex->comm.allreduce_sum(ex->comm.ctx, ex->nrm, 1);
-        dfl_dsqrt_dev(ex->nrm, s);
-    } else dfl_dnrm2(na, QCOL(0), ex->nrm, ex->work, s);
-    HIPGUARD(hipMemcpyAsync(ex->beta, ex->nrm, sizeof(f64), D2D, s)); /* beta[0] = rnrm_init */
-    HIPGUARD(hipMemcpyAsync(&rnrm_init, ex->nrm, sizeof(f64), D2H, s));
-    HIPGUARD(hipStreamSynchronize(s));
-    ex->stats.rnrm_init = rnrm_init;
     ex->stats.converged = FALSE;
-    if (ex->verbose)
-        fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", 0, rnrm_init, atol, 1.0, rtol);
-    if (rnrm_init == 0.0) { /* x already solves the system: the reference would normalise by zero here (krylov.c:130) */
-        ex->stats.iterations = 0;
-        ex->stats.converged = TRUE;
-        return;
-    }
+    ex->stats.iterations = 0;
+    for (index_type cycle = 0; !converged && total < maxit; ++cycle) {
+        f64* res_hist = ex->res_hist + total; /* history of this cycle */
+        index_type iter = 0;
+        HIPGUARD(hipMemsetAsync(H, 0, (size_t)ldh * m * sizeof(f64), s));
+        HIPGUARD(hipMemsetAsync(ex->beta, 0, ((size_t)m + 1) * sizeof(f64), s));
+        HIPGUARD(hipMemsetAsync(ex->gv, 0, 2 * (size_t)m * sizeof(f64), s));
 
-    /* the normalisation of Q[:,k] is folded into the preconditioner application that consumes it;
-       nrm[k] holds the norm Q[:,k] still has to be divided by */
-    while (!converged && iter < maxit) {
-        /* 2.0 tmp = inv(P) Q[:,iter]   2.2 Q[:,iter+1] = A tmp */
-        DFL_TIMED(DFL_TAG_PC, pc_apply_fused(pc, na, QCOL(iter), ex->nrm + iter, tmp));
-        if (dist && split_rows) {
-            /* interior rows read no ghost entry: they run while the halo is in flight */
-            if (ex->comm.halo_begin) ex->comm.halo_begin(ex->comm.ctx, tmp);
-            else ex->comm.halo_exchange(ex->comm.ctx, tmp);
-            DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, tmp, QCOL(iter + 1), 0, n_interior));
-            if (ex->comm.halo_begin) ex->comm.halo_end(ex->comm.ctx, tmp);
-            DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, tmp, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A)));
-        } else {
-            if (dist) ex->comm.halo_exchange(ex->comm.ctx, tmp);
-            DFL_TIMED(DFL_TAG_SPMV, MatrixMatVec(A, tmp, QCOL(iter + 1)));
-        }
-        /* 3. classical Gram-Schmidt */
-        if (dist && ex->fused_norm) {
-            /* w itself is column iter+1 of Q: one extra "column" of the dots gives w.w, one all-reduce carries h and w.w */
-            DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 2, Q, na, QCOL(iter + 1), HCOL(iter), ex->work, s));
-            ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 2);
-            DFL_TIMED(DFL_TAG_CGS_UPDATE, dfl_cgs_update(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), NULL, 0, ex->work, s));
-            dfl_gmres_givens_pythagoras(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, ex->res_hist, ex->d_flag, s);
-            goto arnoldi_step_done;
-        }
-        DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 1, Q, na, QCOL(iter + 1), HCOL(iter), ex->work, s));
-        if (dist) ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 1);
-        /* 4. Givens rotations + residual recurrence, on the device */
+        /* 0. r = b - A x  (krylov.c:112-116) */
+        dfl_dcopy(na, b, QCOL(0), s);
+        if (dist) ex->comm.halo_exchange(ex->comm.ctx, x);
+        if (!(cycle == 0 && x_is_zero)) MatrixAMVPBY(A, -1.0, x, 1.0, QCOL(0));
         if (dist) {
-            DFL_TIMED(DFL_TAG_CGS_UPDATE,
-                      dfl_cgs_update(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), ex->nrm + iter + 1, 0, ex->work, s));
-            ex->comm.allreduce_sum(ex->comm.ctx, ex->nrm + iter + 1, 1);
-            dfl_gmres_givens_sq(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, ex->res_hist, s);
-        } else {
-            DFL_TIMED(DFL_TAG_CGS_UPDATE, dfl_cgs_update_givens(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), ex->nrm + iter + 1,
-                                                                ex->work, iter, H, ldh, ex->gv, ex->beta, ex->res_hist, s));
-        }
-    arnoldi_step_done:
-        if ((iter + 1) % ex->check_interval == 0) {
-            HIPGUARD(hipMemcpyAsync(&rnrm, ex->beta + iter + 1, sizeof(f64), D2H, s));
-            HIPGUARD(hipStreamSynchronize(s));
-            rnrm = fabs(rnrm);
-            if (ex->verbose) {
-                fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", iter + 1, rnrm, atol,
-                        rnrm / (rnrm_init + DBL_EPSILON), rtol);
-                fflush(stdout);
+            zero_ghost_rows(ex, A, QCOL(0), na);
+            dfl_ddot(na, QCOL(0), QCOL(0), ex->nrm, ex->work, s);
+            ex->comm.allreduce_sum(ex->comm.ctx, ex->nrm, 1);
+            dfl_dsqrt_dev(ex->nrm, s);
+        } else dfl_dnrm2(na, QCOL(0), ex->nrm, ex->work, s);
+        HIPGUARD(hipMemcpyAsync(ex->beta, ex->nrm, sizeof(f64), D2D, s)); /* beta[0] = ||r|| */
+        HIPGUARD(hipMemcpyAsync(&rnrm, ex->nrm, sizeof(f64), D2H, s));
+        HIPGUARD(hipStreamSynchronize(s));
+        if (cycle == 0) {
+            rnrm_init = rnrm;
+            ex->stats.rnrm_init = rnrm_init;
+            if (ex->verbose)
+                fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", 0, rnrm_init, atol, 1.0, rtol);
+            if (rnrm_init == 0.0) { /* x already solves the system: the reference would normalise by zero here (krylov.c:130) */
+                ex->stats.converged = TRUE;
+                return;
             }
-            if (rnrm < atol || rnrm < (rnrm_init + 1e-16) * rtol) converged = TRUE;
+        } else {
+            /* restart: the recomputed true residual decides */
+            if (ex->verbose)
+                fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e) [restart %d]\n", total, rnrm, atol,
+                        rnrm / (rnrm_init + DBL_EPSILON), rtol, cycle);
+            if (rnrm < atol || rnrm < (rnrm_init + 1e-16) * rtol) { converged = TRUE; break; }
         }
-        iter++;
-    }
 
-    if (iter) {
-        /* 5.1 H y = beta   5.2 tmp = Q[:,0:iter] y   5.3 precondition   5.4 x += . */
-        dfl_gmres_trsv(iter, H, ldh, ex->beta, s);
-        /* column `iter` may still be un-normalised, but it is not used; columns < iter are normalised */
-        dfl_gemv_n(na, iter, Q, na, ex->beta, tmp, s);
-        pc_apply_fused(pc, na, tmp, NULL, tmp + n);
-        dfl_daxpy(na, 1.0, tmp + n, x, s);
+        /* the normalisation of Q[:,k] is folded into the preconditioner application that consumes it;
+           nrm[k] holds the norm Q[:,k] still has to be divided by */
+        while (!converged && iter < m && total < maxit) {
+            /* 2.0 tmp = inv(P) Q[:,iter]   2.2 Q[:,iter+1] = A tmp */
+            DFL_TIMED(DFL_TAG_PC, pc_apply_fused(pc, na, QCOL(iter), ex->nrm + iter, tmp));
+            if (dist && split_rows) {
+                /* interior rows read no ghost entry: they run while the halo is in flight */
+                if (ex->comm.halo_begin) ex->comm.halo_begin(ex->comm.ctx, tmp);
+                else ex->comm.halo_exchange(ex->comm.ctx, tmp);
+                DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, tmp, QCOL(iter + 1), 0, n_interior));
+                if (ex->comm.halo_begin) ex->comm.halo_end(ex->comm.ctx, tmp);
+                DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, tmp, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A)));
+            } else {
+                if (dist) ex->comm.halo_exchange(ex->comm.ctx, tmp);
+                DFL_TIMED(DFL_TAG_SPMV, MatrixMatVec(A, tmp, QCOL(iter + 1)));
+            }
+            /* 3. classical Gram-Schmidt */
+            if (dist && ex->fused_norm) {
+                /* w itself is column iter+1 of Q: one extra "column" of the dots gives w.w, one all-reduce carries h and w.w */
+                DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 2, Q, na, QCOL(iter + 1), HCOL(iter), ex->work, s));
+                ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 2);
+                DFL_TIMED(DFL_TAG_CGS_UPDATE, dfl_cgs_update(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), NULL, 0, ex->work, s));
+                dfl_gmres_givens_pythagoras(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, res_hist, ex->d_flag, s);
+                goto arnoldi_step_done;
+            }
+            DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 1, Q, na, QCOL(iter + 1), HCOL(iter), ex->work, s));
+            if (dist) ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 1);
+            /* 4. Givens rotations + residual recurrence, on the device */
+            if (dist) {
+                DFL_TIMED(DFL_TAG_CGS_UPDATE,
+                          dfl_cgs_update(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), ex->nrm + iter + 1, 0, ex->work, s));
+                ex->comm.allreduce_sum(ex->comm.ctx, ex->nrm + iter + 1, 1);
+                dfl_gmres_givens_sq(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, res_hist, s);
+            } else {
+                DFL_TIMED(DFL_TAG_CGS_UPDATE, dfl_cgs_update_givens(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), ex->nrm + iter + 1,
+                                                                    ex->work, iter, H, ldh, ex->gv, ex->beta, res_hist, s));
+            }
+        arnoldi_step_done:
+            if ((total + 1) % ex->check_interval == 0) {
+                HIPGUARD(hipMemcpyAsync(&rnrm, ex->beta + iter + 1, sizeof(f64), D2H, s));
+                HIPGUARD(hipStreamSynchronize(s));
+                rnrm = fabs(rnrm);
+                if (ex->verbose) {
+                    fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", total + 1, rnrm, atol,
+                            rnrm / (rnrm_init + DBL_EPSILON), rtol);
+                    fflush(stdout);
+                }
+                if (rnrm < atol || rnrm < (rnrm_init + 1e-16) * rtol) converged = TRUE;
+            }
+            iter++;
+            total++;
+        }
+
+        if (iter) {
+            /* 5.1 H y = beta   5.2 tmp = Q[:,0:iter] y   5.3 precondition   5.4 x += . */
+            dfl_gmres_trsv(iter, H, ldh, ex->beta, s);
+            /* column `iter` may still be un-normalised, but it is not used; columns < iter are normalised */
+            dfl_gemv_n(na, iter, Q, na, ex->beta, tmp, s);
+            pc_apply_fused(pc, na, tmp, NULL, tmp + n);
+            dfl_daxpy(na, 1.0, tmp + n, x, s);
+        }
     }
-    index_type nh = iter < 512 ? iter : 512;
+    index_type nh = total < 512 ? total : 512;
     if (nh) HIPGUARD(hipMemcpyAsync(ex->stats.res_hist, ex->res_hist, sizeof(f64) * (size_t)nh, D2H, s));
     ex->stats.fused_norm_cancelled = FALSE;
     if (dist && ex->fused_norm) {
@@ -444,7 +479,7 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
         HIPGUARD(hipMemsetAsync(ex->d_flag, 0, sizeof(int), s));
     }
     HIPGUARD(hipStreamSynchronize(s));
-    ex->stats.iterations = iter;
+    ex->stats.iterations = total;
     ex->stats.converged = converged;
 #undef QCOL
 #undef HCOL
@@ -462,7 +497,7 @@ static void CGSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     const index_type n = MatrixNumRow(A), maxit = ksp->max_iter;
     index_type na = n;
     const b32 dist = ex->has_comm;
-    ws_ensure(ex, n, 3, 32); /* r, z, p, Ap in Q[0..3] */
+    ws_ensure(ex, n, 3, 32, 3); /* r, z, p, Ap in Q[0..3] */
     if (MatrixFSBlockValues(A)) {
         index_type N = ((MatrixFS*)A->data)->spy1x1->num_row;
         b32 tail_zero = FALSE, unused = FALSE;
@@ -474,6 +509,7 @@ static void CGSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     dfl_dcopy(na, b, r, s);
     if (dist) ex->comm.halo_exchange(ex->comm.ctx, x);
     MatrixAMVPBY(A, -1.0, x, 1.0, r);
+    zero_ghost_rows(ex, A, r, na);
     index_type it = 0;
     b32 converged = FALSE;
 #define DOT2(a1, b1, a2, b2)                                                       \

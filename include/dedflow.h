@@ -97,6 +97,9 @@ Allocator* GetDefaultAllocator(int device_id);
 #define CdamFreeHost(ptr, count) (GetDefaultAllocator(HOST)->free(ptr, (ptrdiff_t)(count), GetDefaultAllocator(HOST)->ctx))
 #define CdamMallocDevice(count) (GetDefaultAllocator(DEVICE)->malloc((ptrdiff_t)(count), GetDefaultAllocator(DEVICE)->ctx))
 #define CdamFreeDevice(ptr, count) (GetDefaultAllocator(DEVICE)->free(ptr, (ptrdiff_t)(count), GetDefaultAllocator(DEVICE)->ctx))
+/* the two macros above as functions, for bindings that cannot expand C macros (zero-filled, pooled: host/runtime.c) */
+void* DflDeviceMalloc(int64_t bytes);
+void DflDeviceFree(void* ptr);
 
 /* ---- mesh (MeshData.h, Mesh.h) --------------------------------------------------- */
 typedef struct H5FileInfo H5FileInfo;
@@ -382,6 +385,9 @@ PC* KrylovGetPC(const Krylov* krylov);
  * step needs ONE all-reduce (h and w.w together) instead of two; rounding differs from the explicit norm and heavy
  * cancellation raises KrylovStats.fused_norm_cancelled */
 void KrylovSetFusedNorm(Krylov* krylov, b32 on);
+/* GMRES(m): restart after m basis columns (x updated, true residual recomputed); m <= 0 or m >= max_iter (default) = the
+ * reference's full GMRES.  Keeps the basis at m+1 vectors for long solves (config 5: 50M tets, PC_ILU0). */
+void KrylovSetRestart(Krylov* krylov, index_type m);
 /* optional communicator for element-partitioned runs (one process per GPU); NULL = single GPU */
 typedef struct DflComm {
     void (*allreduce_sum)(void* ctx, f64* d_buf, index_type n); /* in place, device buffer */
@@ -456,6 +462,11 @@ void DflSetPatchParameters(index_type leaf, index_type slot_cap);
 /* schedule 3 (row-owner node patches): nodes per patch and cap on their summed nodal row lengths
  * (one 128-byte LDS line per nodal nonzero; 255 -> 32 KB per workgroup) */
 void DflSetRowPatchParameters(index_type leaf_nodes, index_type slot_cap);
+/*   4  slot-owner node patches for J (host/slotpatch.c): as 3, but every nodal nonzero is summed in registers by its owner
+ *      lanes and written once -- no LDS atomics, fixed summation order (bitwise reproducible), no geometry cache */
+void DflSetSlotPatchParameters(index_type leaf_nodes, index_type slot_cap, index_type tet_cap);
+/* schedule 4 assembles the residual with one wave per patch of <= tets tets / <= nodes nodes: (16,32), (32,48) or (64,64) */
+void DflSetRhsWaveParameters(index_type tets, index_type nodes);
 /* schedules 2 and 3 assemble the residual by spatial tet patches (<= 64 tets, <= node_cap <= 96 distinct nodes each) */
 void DflSetRhsPatchParameters(index_type leaf_tets, index_type node_cap);
 

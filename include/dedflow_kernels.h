@@ -283,6 +283,24 @@ void dfl_assemble_tet_lhs_rowpatch(dfl_index npatch, const dfl_index* p_ioff, co
                                    const unsigned short* item_slot, const dfl_index* slot_nz, const dfl_index* ien,
                                    const dfl_value* egeo, const dfl_value* nodep, dfl_value* val, dfl_value beta,
                                    dfl_index max_slots, void* stream);
+/* slot-owner form (assembly schedule 4, default; host/slotpatch.c, csrc/k_assemble2.hip): workgroup p owns the CSR rows of
+ * its node patch; hdr[p] = {tet_off, num_tet, slot_off, num_slot, contrib_off, num_contrib, 0, 0}; ptet_ien[tet_off + k][4] = node ids of the k-th tet
+ * touching the patch; slot s of the patch is nodal nonzero slot_nz[slot_off + s] and sums the contributions
+ * desc[coff[slot_off + s] .. coff[slot_off + s + 1]) = (local tet << 4) | (a << 2) | b in that order.
+ * val = beta * val + assembled rows (beta = 0 overwrites).  max_tets / max_slots / max_contrib = largest num_tet /
+ * num_slot / num_contrib over the patches (they size the workgroup's LDS: dfl_lhs_slot_lds_bytes).  No atomics:
+ * bitwise reproducible. */
+int dfl_lhs_slot_record_bytes(void);
+int64_t dfl_lhs_slot_lds_bytes(dfl_index max_tets, dfl_index max_slots, dfl_index max_contrib);
+void dfl_assemble_tet_lhs_slot(dfl_index npatch, const int32_t* hdr, const dfl_index* ptet_ien, const dfl_index* slot_nz,
+                               const dfl_index* coff, const unsigned short* desc, const dfl_value* nodep, dfl_value* val,
+                               dfl_value beta, dfl_index max_tets, dfl_index max_slots, dfl_index max_contrib, void* stream);
+/* wave-per-patch form of the residual (schedule 4): the padded layout of host/patch.c -- patch p holds tet slots
+ * [p*pad_tets, ..) of lien / adj, node slots [p*pad_nodes, ..) of pnode / partial and adj_start[p*(pad_nodes+1) ..];
+ * cnt[p] = num_tets | num_nodes << 16.  Supported shapes (pad_tets, pad_nodes): (16,32), (32,48), (64,64). */
+void dfl_assemble_tet_rhs_wave(dfl_index npatch, dfl_index pad_tets, dfl_index pad_nodes, const dfl_index* cnt,
+                               const dfl_index* pnode, const unsigned char* lien, const unsigned short* adj,
+                               const unsigned short* adj_start, const dfl_value* nodep, dfl_value* partial, void* stream);
 /* developer probe of the patch kernel (bit 0 skip element loop, bit 1 skip flush, bit 2 skip LDS adds) */
 void dfl_tune_asm(int flags);
 /* weak-BC faces of one color (src/assemble.cu:1764-1964): face list entries index f2e/forn of the group */

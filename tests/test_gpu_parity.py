@@ -286,7 +286,7 @@ def test_reference_color_schedule_matches_compact_schedule(api, oracle_lib):
     wg, dwg = synthetic_fields(m)
     F, vals = S.assemble_system(wg, dwg, True, True)
     out = []
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 4):
         P = api.Problem(m, schedule=mode)
         try:
             assert np.array_equal(P.color(), S.color) and np.array_equal(P.batch_ind(), S.batch_ind)
@@ -344,6 +344,46 @@ def test_row_owner_schedule_add_and_overwrite(api):
     L.DflSetRowPatchParameters(16, 255)
 
 
+def test_slot_owner_schedule_add_overwrite_and_bitwise_reproducible(api, oracle_lib):
+    """Schedule 4 (default): every nodal nonzero is summed by its owner lanes in a fixed order.  AssembleSystemTet keeps
+    the reference's additive contract, AssembleSystem overwrites, two runs agree BITWISE (like the reference's colored
+    scatter), and the values match the oracle for every patch size (incl. 1-node patches and tet-capped patches)."""
+    m = kuhn_cube(7, jitter=0.2)
+    wg, dwg = synthetic_fields(m)
+    S = oracle_lib.System(m)
+    _, vals = S.assemble_system(wg, dwg, False, True)
+    L = api.lib()
+    try:
+        for leaf, cap, tcap in ((16, 255, 208), (1, 40, 64), (5, 60, 40), (64, 1023, 500)):
+            L.DflSetSlotPatchParameters(leaf, cap, tcap)
+            P = api.Problem(m, schedule=4)
+            try:
+                wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+                L.MatrixZero(P.J)
+                P.assemble_tet(wg_d, dwg_d, None, want_J=True)
+                api.sync()
+                v1 = P.block_values().numpy().copy()
+                P.assemble_tet(wg_d, dwg_d, None, want_J=True)
+                api.sync()
+                v2 = P.block_values().numpy().copy()
+                assert np.abs(v2 - 2.0 * v1).max() <= 1e-13 * np.abs(v1).max()
+                P.assemble_system(wg_d, dwg_d, None, want_J=True)   # J holds 2x: must be overwritten, then faces + BC rows
+                api.sync()
+                v3 = P.block_values().numpy().copy()
+                L.MatrixZero(P.J)
+                P.assemble_system(wg_d, dwg_d, None, want_J=True)
+                api.sync()
+                v4 = P.block_values().numpy().copy()
+                assert np.array_equal(v3, v4), "slot-owner assembly is not bitwise reproducible"
+                for g, o in zip(P.export_values(), vals):
+                    ok, err = close(g, o)
+                    assert ok, (leaf, cap, tcap, err)
+            finally:
+                P.close()
+    finally:
+        L.DflSetSlotPatchParameters(16, 255, 208)
+
+
 def test_patch_residual_is_reproducible_and_patch_size_independent(api, oracle_lib):
     """Schedules 2/3 assemble F by spatial tet patches with a fixed summation order: bitwise equal run to run,
     equal to the oracle within the parity bar for every patch size (incl. 1-tet patches and ragged tails)."""
@@ -371,6 +411,35 @@ def test_patch_residual_is_reproducible_and_patch_size_independent(api, oracle_l
                 P.close()
     finally:
         L.DflSetRhsPatchParameters(64, 64)
+
+
+def test_wave_residual_is_reproducible_and_shape_independent(api, oracle_lib):
+    """Schedule 4 assembles F with one wave per spatial patch (padded layout, no workgroup barriers): bitwise equal run to
+    run, equal to the oracle within the parity bar for every supported patch shape."""
+    m = kuhn_cube(7, jitter=0.2)
+    S = oracle_lib.System(m)
+    wg, dwg = synthetic_fields(m)
+    F, _ = S.assemble_system(wg, dwg, True, False)
+    L = api.lib()
+    try:
+        for tets, nodes in ((32, 48), (16, 32), (64, 64)):
+            L.DflSetRhsWaveParameters(tets, nodes)
+            P = api.Problem(m, schedule=4)
+            try:
+                wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+                runs = []
+                for rep in range(2):
+                    F_d = api.DeviceArray(6 * S.N)
+                    P.assemble_system(wg_d, dwg_d, F_d, want_J=False)
+                    api.sync()
+                    runs.append(F_d.numpy().copy())
+                assert np.array_equal(runs[0], runs[1])
+                ok, err = close(runs[0], F)
+                assert ok, (tets, nodes, err)
+            finally:
+                P.close()
+    finally:
+        L.DflSetRhsWaveParameters(32, 48)
 
 
 def test_geometry_cache_follows_moved_nodes(api, oracle_lib):

@@ -1,5 +1,5 @@
-"""A/B of the Jacobian-assembly schedules (1 = compact colors, 2 = tet patches, 3 = row-owner node patches) at M
-(default 119); extra args are mode:leaf:cap triples."""
+"""A/B of the Jacobian-assembly schedules (1 = compact colors, 2 = tet patches, 3 = row-owner node patches, 4 = slot-owner
+node patches) at M (default 119); extra args are mode:leaf:cap[:tetcap] tuples."""
 import ctypes as C, sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,16 +7,21 @@ from dedflow_amd import api
 from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 119
-configs = [(1, 0, 0)] + [(int(m), int(a), int(b)) for m, a, b in (c.split(":") for c in sys.argv[2:])] if len(sys.argv) > 2 else [(1, 0, 0), (2, 64, 320), (3, 16, 255)]
+def parse(c):
+    v = [int(k) for k in c.split(":")]
+    return (v[0], v[1], v[2], v[3] if len(v) > 3 else 208)
+configs = [(1, 0, 0, 0)] + [parse(c) for c in sys.argv[2:]] if len(sys.argv) > 2 else [(1, 0, 0, 0), (3, 16, 255, 0), (4, 16, 255, 208)]
 mesh = kuhn_cube(M, jitter=0.2)
 wg, dwg = synthetic_fields(mesh)
 L = api.lib()
 ref = None
-for mode, leaf, cap in configs:
+for mode, leaf, cap, tcap in configs:
     if mode == 2:
         L.DflSetPatchParameters(leaf, cap)
     if mode == 3:
         L.DflSetRowPatchParameters(leaf, cap)
+    if mode == 4:
+        L.DflSetSlotPatchParameters(leaf, cap, tcap)
     t0 = time.perf_counter()
     P = api.Problem(mesh, schedule=mode)
     wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
@@ -41,6 +46,6 @@ for mode, leaf, cap in configs:
         ref = v
     err = np.abs(v - ref).max() / np.abs(ref).max()
     ms = float(np.median(res))
-    print("mode %d leaf %d cap %d: J assembly median %.3f ms (min %.3f)  %.3g DOF/s  setup %.1f s  rel diff vs mode 1: %.2e" %
-          (mode, leaf, cap, ms, min(res), 4.0 * P.N / (ms * 1e-3), t_setup, err), flush=True)
+    print("mode %d leaf %d cap %d tcap %d: J assembly median %.3f ms (min %.3f)  %.3g DOF/s  setup %.1f s  rel diff vs mode 1: %.2e" %
+          (mode, leaf, cap, tcap, ms, min(res), 4.0 * P.N / (ms * 1e-3), t_setup, err), flush=True)
     P.close()

@@ -1,5 +1,5 @@
-"""A/B of the residual-assembly paths at M (default 119): schedule 1 (colored launches) vs patch form (schedule 3);
-extra args are leaf:node_cap pairs for the patch form."""
+"""A/B of the residual-assembly paths at M (default 119): schedule 1 (colored launches), patch form (schedule 3, args
+leaf:node_cap) and wave-per-patch form (schedule 4, args w:tets:nodes)."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,8 +7,13 @@ from dedflow_amd import api
 from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 119
-cfgs = [(1, 0, 0)] + [(3,) + tuple(int(v) for v in c.split(":")) for c in (sys.argv[2:] or ["64:64"])]
-cfgs = [c if len(c) == 4 else c + (0,) for c in cfgs]
+def parse(c):
+    if c.startswith("w:"):
+        v = [int(k) for k in c[2:].split(":")]
+        return (4, v[0], v[1], 0)
+    v = [int(k) for k in c.split(":")]
+    return (3, v[0], v[1], v[2] if len(v) > 2 else 0)
+cfgs = [(1, 0, 0, 0)] + [parse(c) for c in (sys.argv[2:] or ["64:64", "w:32:48", "w:64:64", "w:16:32"])]
 mesh = kuhn_cube(M, jitter=0.2)
 wg, dwg = synthetic_fields(mesh)
 L = api.lib()
@@ -17,6 +22,8 @@ for mode, leaf, cap, dbg in cfgs:
     L.dfl_tune_asm(dbg)
     if mode == 3:
         L.DflSetRhsPatchParameters(leaf, cap)
+    if mode == 4:
+        L.DflSetRhsWaveParameters(leaf, cap)
     P = api.Problem(mesh, schedule=mode)
     wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
     F_d = api.DeviceArray(6 * P.N)

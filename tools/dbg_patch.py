@@ -5,18 +5,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dedflow_amd import api
 from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 119
-mode, leaf, cap = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "2:64:320").split(":"))
+cfg = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "2:64:320").split(":")]
+mode, leaf, cap = cfg[:3]
 mesh = kuhn_cube(M, jitter=0.2)
 wg, dwg = synthetic_fields(mesh)
 L = api.lib()
-(L.DflSetPatchParameters if mode == 2 else L.DflSetRowPatchParameters)(leaf, cap)
+if mode == 4:
+    L.DflSetSlotPatchParameters(leaf, cap, cfg[3] if len(cfg) > 3 else 208)
+else:
+    (L.DflSetPatchParameters if mode == 2 else L.DflSetRowPatchParameters)(leaf, cap)
 P = api.Problem(mesh, schedule=mode)
 wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
 L.MatrixZero(P.J)
 P.assemble_tet(wg_d, dwg_d, None, want_J=True)
 api.sync()
 REPS = int(os.environ.get('DFL_DBG_REPS', 20))
-seq = (0,) if len(sys.argv) > 3 else (0, 8, 2, 10, 1, 3, 0)
+seq = (0,) if len(sys.argv) > 3 else ((0, 1, 2, 4, 6, 8, 0) if mode == 4 else (0, 8, 2, 10, 1, 3, 0))
 for dbg in seq:
     L.dfl_tune_asm(dbg)
     for rep in range(3):
