@@ -192,7 +192,8 @@ class MatrixFS(C.Structure):
 
 class KrylovStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("rnrm_init", C.c_double), ("res_hist", C.c_double * 512), ("converged", C.c_int32),
-                ("fused_norm_cancelled", C.c_int32)]
+                ("fused_norm_cancelled", C.c_int32), ("total_solves", C.c_int32), ("total_converged", C.c_int32),
+                ("total_iterations", C.c_int64)]
 
 
 class Dirichlet(C.Structure):
@@ -260,6 +261,8 @@ def _declare(L):
     f("DflStream", vp, []); f("DflSetStream", None, [vp]); f("DflSetQuiet", None, [i32])
     f("DflSetAssemblySchedule", None, [C.c_int]); f("DflSetPatchParameters", None, [i32, i32])
     f("DflSetRowPatchParameters", None, [i32, i32]); f("dfl_tune_asm", None, [C.c_int])
+    f("DflMeshSetAssemblySchedule", None, [C.POINTER(Mesh3D), C.c_int]); f("DflMeshSetWeakBCGroup", None, [C.POINTER(Mesh3D), i32])
+    f("DflSetWeakBCGroup", None, [i32])
     f("DflSetSlotPatchParameters", None, [i32, i32, i32]); f("DflSetRhsWaveParameters", None, [i32, i32])
     f("DflSetRhsPatchParameters", None, [i32, i32]); f("DflMeshGeometryChanged", None, [C.POINTER(Mesh3D)])
     f("Mesh3DCreate", C.POINTER(Mesh3D), [i32, i32, i32, i32]); f("Mesh3DDestroy", None, [C.POINTER(Mesh3D)])
@@ -273,7 +276,11 @@ def _declare(L):
     f("MatrixZero", None, [C.POINTER(Matrix)])
     f("MatrixAMVPBY", None, [C.POINTER(Matrix), f64, vp, f64, vp]); f("MatrixMatVec", None, [C.POINTER(Matrix), vp, vp])
     f("MatrixGetDiag", None, [C.POINTER(Matrix), vp, i32])
-    f("MatrixFSBlockValues", vp, [C.POINTER(Matrix)])
+    f("MatrixFSBlockValues", vp, [C.POINTER(Matrix)]); f("MatrixFSUseReferenceLayout", None, [C.POINTER(Matrix), i32])
+    f("MatrixAddElemValueBlockedBatched", None, [C.POINTER(Matrix), i32, i32, vp, vp, i32, i32, vp, C.c_int, C.c_int, vp])
+    f("MatrixMatVecWithMask", None, [C.POINTER(Matrix), vp, vp, vp, vp]); f("MatrixZeroRow", None, [C.POINTER(Matrix), i32, vp, i32, f64])
+    f("VecAXPY", None, [f64, vp, vp, i32]); f("VecPointwiseMult", None, [vp, vp, vp, i32]); f("VecPointwiseDiv", None, [vp, vp, vp, i32])
+    f("VecPointwiseInv", None, [vp, i32])
     f("MatrixFSExportSubmatrices", None, [C.POINTER(Matrix)]); f("MatrixFSImportSubmatrices", None, [C.POINTER(Matrix)])
     f("DirichletCreate", C.POINTER(Dirichlet), [C.POINTER(Mesh3D), i32, i32]); f("DirichletDestroy", None, [C.POINTER(Dirichlet)])
     f("DirichletApplyVec", None, [C.POINTER(Dirichlet), vp]); f("DirichletApplyMat", None, [C.POINTER(Dirichlet), C.POINTER(Matrix)])
@@ -282,6 +289,7 @@ def _declare(L):
     f("KrylovGetStats", C.POINTER(KrylovStats), [vp]); f("KrylovSetCheckInterval", None, [vp, i32])
     f("KrylovSetVerbose", None, [vp, i32]); f("KrylovSetComm", None, [vp, C.POINTER(DflComm)])
     f("PCSetup", None, [vp]); f("PCApply", None, [vp, vp, vp]); f("PCDestroy", None, [vp])
+    f("PCCreateJacobi", vp, [C.POINTER(Matrix), i32, vp]); f("PCCreateNone", vp, [C.POINTER(Matrix), i32])
     f("PCCreateDILU", vp, [C.POINTER(Matrix)]); f("PCDILUGetColors", i32, [vp, vp]); f("PCDILUGetInverseBlocks", vp, [vp])
     f("KrylovSetPCType", None, [vp, C.c_int]); f("KrylovGetPC", vp, [vp]); f("KrylovSetFusedNorm", None, [vp, C.c_int]); f("KrylovSetRestart", None, [vp, i32])
     f("AssembleSystemTet", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix)])
@@ -305,6 +313,7 @@ def _declare(L):
     f("SolveFlowSystem", i32, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix), vp, vp, vp, vp, i32, i32, vp, vp])
     f("DflTimeStep", i32, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix), vp, vp, vp, vp, i32, i32, C.POINTER(ParticleContext),
                            i32, vp, vp])
+    f("DflDevicePoolStats", None, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
     f("DflProfileEnable", None, [C.c_int]); f("DflProfileCollect", C.c_int, [C.c_int, C.POINTER(f64), C.POINTER(f64)])
     f("GenerateRandomColor", None, [vp, i32, i32])
     f("dfl_abi_version", C.c_int, [])
@@ -317,7 +326,8 @@ REFERENCE_BCS = [(0, (1, 1, 1)), (2, (0, 1, 0)), (3, (0, 0, 1)), (4, (0, 0, 0))]
 class Problem:
     """The reference driver's setup sequence (src/main.c:362-477) through the C API."""
 
-    def __init__(self, mesh, maxit=120, atol=1e-12, rtol=1e-4, quiet=True, bcs=REFERENCE_BCS, color=True, schedule=3):
+    def __init__(self, mesh, maxit=120, atol=1e-12, rtol=1e-4, quiet=True, bcs=REFERENCE_BCS, color=True, schedule=4,
+                 reference_layout=False):
         L = lib()
         L.Init(0, None)
         L.DflSetQuiet(1 if quiet else 0)
@@ -343,6 +353,8 @@ class Problem:
         fs.mat[1] = L.MatrixCreateTypeCSR(self.spy3x1, None)
         fs.mat[4] = L.MatrixCreateTypeCSR(self.spy1x3, None)
         fs.mat[5] = L.MatrixCreateTypeCSR(self.spy1x1, None)
+        if reference_layout:
+            L.MatrixFSUseReferenceLayout(self.J, 1)
         L.MatrixSetup(self.J)
         self.fs = fs
         self.nnz1 = int(self.spy1x1.contents.nnz)
@@ -385,7 +397,7 @@ class Problem:
 
     def export_values(self):
         """The four sub-matrix value arrays in the reference layout (A00, A01, A10, A11)."""
-        lib().MatrixFSExportSubmatrices(self.J)
+        lib().MatrixFSExportSubmatrices(self.J)   # no-op unless block mode
         sync()
         out = []
         for slot, mult in ((0, 9), (1, 3), (4, 3), (5, 1)):

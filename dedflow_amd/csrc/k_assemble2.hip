@@ -23,150 +23,232 @@ constexpr int SP_RS = 34;  // doubles per LDS tet record: shg[12] conv[a][q] (16
 
 typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
 
-// Dynamic LDS of one workgroup: [max_tets] tet records | [max_slots + 1] contribution offsets (relative to the patch) |
-// [max_slots] nodal nonzero of each slot | [max_contrib] contribution descriptors -- the three lists are staged with
-// coalesced loads while the node records of phase 1 are in flight, so phase 2 never waits on HBM.
+// Dynamic LDS of one workgroup: [max_tets] tet records | 2 x { [max_slots + 1] contribution offsets (relative to the
+// patch) | [max_slots] nodal nonzero of each slot | [max_contrib] contribution descriptors }.  The workgroups are
+// PERSISTENT (grid = resident workgroups; each walks its share of the patches) and software-pipelined: while phase 2 of
+// patch p runs, the node records of the next patch are in flight into registers and its three lists sit in registers
+// waiting for the second list buffer, so neither phase 1 nor phase 2 waits on HBM and the row stores of patch p drain
+// behind the work on patch p+1.
+__host__ __device__ inline size_t slot_list_bytes(int max_slots, int max_contrib) {
+    return (size_t)(((2 * max_slots + 1) * 4 + 15) & ~15) + (size_t)((max_contrib * 2 + 15) & ~15);
+}
 __host__ __device__ inline size_t slot_lds_bytes(int max_tets, int max_slots, int max_contrib) {
-    return (size_t)max_tets * SP_RS * 8 + (size_t)(((2 * max_slots + 1) * 4 + 15) & ~15) + (size_t)((max_contrib * 2 + 15) & ~15);
+    return (size_t)max_tets * SP_RS * 8 + 2 * slot_list_bytes(max_slots, max_contrib);
+}
+
+__device__ __forceinline__ void slot_load_records(const T* __restrict__ nodep, const int4& nd, double2* r) {
+    const int node[4] = {nd.x, nd.y, nd.z, nd.w};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {  // packed node record: x at [0..2], u at [3..5]
+        const double2* rp = reinterpret_cast<const double2*>(nodep + (long long)node[b] * 16);
+        r[3 * b] = rp[0];
+        r[3 * b + 1] = rp[1];
+        r[3 * b + 2] = rp[2];
+    }
+}
+
+// phase 1 of one tet: everything its sixteen (a,b) blocks share -> one LDS record
+__device__ __forceinline__ void slot_tet_record(const double2* r, double* rec) {
+    double x[12], u[12];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        x[b * 3] = r[3 * b].x; x[b * 3 + 1] = r[3 * b].y; x[b * 3 + 2] = r[3 * b + 1].x;
+        u[b * 3] = r[3 * b + 1].y; u[b * 3 + 1] = r[3 * b + 2].x; u[b * 3 + 2] = r[3 * b + 2].y;
+    }
+    double invJ[9], shg[12], G[9], detJ;
+    tet_geometry(x, invJ, detJ, shg);
+    tet_metric(shg, G);
+    double gg = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gg += G[k] * G[k];
+    const double itr = 1.0 / (G[0] + G[4] + G[8]);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) rec[k] = shg[k];
+    double su[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) su[d] = ((u[d] + u[3 + d]) + u[6 + d]) + u[9 + d];
+    const double knu = kMU / kRHO;
+    double s_t1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // u at quadrature point q (qr_wgalpha, :1648-1655): shl(b,q) = SHB + (SHA-SHB)[b == q]
+        double uq[3], cv[4];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) uq[d] = SHB * su[d] + (SHA - SHB) * u[q * 3 + d];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {  // shconv (:574-583)
+            cv[a] = shg[a * 3] * uq[0] + shg[a * 3 + 1] * uq[1] + shg[a * 3 + 2] * uq[2];
+            rec[12 + a * 4 + q] = cv[a];
+        }
+        // |J^-1 u|^2 (rows of J^-1 = shape gradients of nodes 1..3) and the stabilisation parameters (:587-603)
+        const double y = cv[1] * cv[1] + cv[2] * cv[2] + cv[3] * cv[3] + (3.0 * knu * knu) * gg;
+        rec[28 + q] = rsqrt(4.0 / (kDT * kDT) + y) * (1.0 / kRHO);
+        s_t1 += y * rsqrt(y) * itr;  // tauC enters the block only through its sum over the quadrature points
+    }
+    rec[32] = s_t1;
+    rec[33] = detJ;
 }
 
 // PROBE = true only under dfl_tune_asm (developer phase split: bit 0 skip phase 2, bit 1 skip phase 1, bit 2 skip the
 // block evaluation, bit 3 skip the store); the shipped instantiation carries no probe branches
-template <bool BETA0, bool PROBE>
-__global__ __launch_bounds__(SBLK) void tet_lhs_slot_kernel(I P, const int4* __restrict__ hdr, const int4* __restrict__ ptet_ien,
+// EARLY: the node records of the next patch are requested before phase 2 (they fly during it, at the price of 48 more
+// live registers: 2 waves per SIMD); otherwise after it (their latency is covered by the other resident workgroups)
+template <bool BETA0, bool PROBE, bool EARLY>
+__global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, const int4* __restrict__ hdr, const int4* __restrict__ ptet_ien,
                                                            const I* __restrict__ slot_nz, const I* __restrict__ coff,
                                                            const unsigned short* __restrict__ desc,
                                                            const T* __restrict__ nodep, T* __restrict__ val, T beta,
-                                                           int max_tets, int max_slots, int dbg_in) {
+                                                           int max_tets, int max_slots, int max_contrib, int dbg_in) {
     const int dbg = PROBE ? dbg_in : 0;
     extern __shared__ __attribute__((aligned(16))) double s_tet[];
-    int* s_coff = reinterpret_cast<int*>(s_tet + (size_t)max_tets * SP_RS);
-    int* s_nz = s_coff + max_slots + 1;
-    unsigned short* s_desc = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(s_coff) + (((2 * max_slots + 1) * 4 + 15) & ~15));
+    char* const s_lists = reinterpret_cast<char*>(s_tet + (size_t)max_tets * SP_RS);
+    const int lbytes = (int)slot_list_bytes(max_slots, max_contrib);
+    const int desc_off = ((2 * max_slots + 1) * 4 + 15) & ~15;
     // XCD-aware order: workgroup w runs on XCD w % 8; every XCD gets one contiguous range of the spatially ordered
-    // patches, so neighbouring patches (which share tets and node records) share an L2
+    // patches (neighbouring patches share tets and node records -> one L2), dealt round-robin to its workgroups
     const int per = (P + 7) >> 3;
-    const int pid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (pid >= P) return;
+    const int g8 = gridDim.x >> 3;
+    const int pbeg = (blockIdx.x & 7) * per;
+    const int pend = min((int)P, pbeg + per);
+    int p = pbeg + (blockIdx.x >> 3);
+    if (p >= pend) return;
     const int t = threadIdx.x;
-    const int4 h = hdr[2 * pid], h2 = hdr[2 * pid + 1];
-    const int t0 = h.x, nt = h.y, s0 = h.z, ns = h.w, c0 = h2.x, nc = h2.y;
+    const int4 zero4 = make_int4(0, 0, 0, 0);
 
-    // hop 2 of the load chain: connectivity of this lane's tet next to the three lists of the patch
-    int4 nd = make_int4(0, 0, 0, 0);
-    if (t < nt) nd = ptet_ien[t0 + t];
-    for (int k = t; k <= ns; k += SBLK) s_coff[k] = coff[s0 + k] - c0;
-    for (int k = t; k < ns; k += SBLK) s_nz[k] = slot_nz[s0 + k];
-    {   // c0 is a multiple of 4 descriptors (8 bytes)
-        const uint2* src = reinterpret_cast<const uint2*>(desc + c0);
-        uint2* dst = reinterpret_cast<uint2*>(s_desc);
-        for (int k = t; k < (nc + 3) >> 2; k += SBLK) dst[k] = src[k];
+    // ---- prologue: lists of the first patch straight into buffer 0, its node records into registers -----------------
+    int4 h = hdr[2 * p], h2 = hdr[2 * p + 1];
+    {
+        int* lc = reinterpret_cast<int*>(s_lists);
+        int* lz = lc + max_slots + 1;
+        uint2* ld = reinterpret_cast<uint2*>(s_lists + desc_off);
+        if (t <= h.w) lc[t] = coff[h.z + t] - h2.x;
+        if (t < h.w) lz[t] = slot_nz[h.z + t];
+        const uint2* src = reinterpret_cast<const uint2*>(desc + h2.x);  // h2.x is a multiple of 4 descriptors (8 bytes)
+        for (int k = t; k < (h2.y + 3) >> 2; k += SBLK) ld[k] = src[k];
     }
+    double2 r[12];
+    int4 nd = zero4;
+    if (t < h.y) nd = ptet_ien[h.x + t];
+    if (EARLY && t < h.y) slot_load_records(nodep, nd, r);
+    int pn = p + g8;
+    int4 hn = zero4, hn2 = zero4;
+    if (pn < pend) { hn = hdr[2 * pn]; hn2 = hdr[2 * pn + 1]; }
+    int buf = 0;
 
-    // ---- phase 1: one lane per (patch, tet) ------------------------------------------------------------------
-    for (int lt = t; lt < ((dbg & 2) ? 0 : nt); lt += SBLK) {
-        if (lt >= SBLK) nd = ptet_ien[t0 + lt];
-        const int node[4] = {nd.x, nd.y, nd.z, nd.w};
-        double x[12], u[12];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {  // packed node record: x at [0..2], u at [3..5]
-            const double2* r = reinterpret_cast<const double2*>(nodep + (long long)node[b] * 16);
-            const double2 v0 = r[0], v1 = r[1], v2 = r[2];
-            x[b * 3] = v0.x; x[b * 3 + 1] = v0.y; x[b * 3 + 2] = v1.x;
-            u[b * 3] = v1.y; u[b * 3 + 1] = v2.x; u[b * 3 + 2] = v2.y;
+    for (;;) {
+        const bool has_next = pn < pend;
+        const int nt = h.y, ns = h.w;
+        // (a) hop 2 for the next patch: connectivity of this lane's tet + the three lists, into registers
+        int4 ndn = zero4;
+        int n_c = 0, n_z = 0;
+        uint2 n_d0 = make_uint2(0, 0), n_d1 = make_uint2(0, 0);
+        int pnn = pn + g8;
+        int4 hnn = zero4, hnn2 = zero4;
+        if (has_next) {
+            if (t < hn.y) ndn = ptet_ien[hn.x + t];
+            if (t <= hn.w) n_c = coff[hn.z + t] - hn2.x;
+            if (t < hn.w) n_z = slot_nz[hn.z + t];
+            const uint2* src = reinterpret_cast<const uint2*>(desc + hn2.x);
+            const int nq = (hn2.y + 3) >> 2;
+            if (t < nq) n_d0 = src[t];
+            if (t + SBLK < nq) n_d1 = src[t + SBLK];
+            if (pnn < pend) { hnn = hdr[2 * pnn]; hnn2 = hdr[2 * pnn + 1]; }
         }
-        double invJ[9], shg[12], G[9], detJ;
-        tet_geometry(x, invJ, detJ, shg);
-        tet_metric(shg, G);
-        double gg = 0.0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) gg += G[k] * G[k];
-        const double itr = 1.0 / (G[0] + G[4] + G[8]);
-        double* rec = s_tet + lt * SP_RS;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) rec[k] = shg[k];
-        double su[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) su[d] = ((u[d] + u[3 + d]) + u[6 + d]) + u[9 + d];
-        const double knu = kMU / kRHO;
-        double s_t1 = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            // u at quadrature point q (qr_wgalpha, :1648-1655): shl(b,q) = SHB + (SHA-SHB)[b == q]
-            double uq[3], cv[4];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) uq[d] = SHB * su[d] + (SHA - SHB) * u[q * 3 + d];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {  // shconv (:574-583)
-                cv[a] = shg[a * 3] * uq[0] + shg[a * 3 + 1] * uq[1] + shg[a * 3 + 2] * uq[2];
-                rec[12 + a * 4 + q] = cv[a];
-            }
-            // |J^-1 u|^2 (rows of J^-1 = shape gradients of nodes 1..3) and the stabilisation parameters (:587-603)
-            const double y = cv[1] * cv[1] + cv[2] * cv[2] + cv[3] * cv[3] + (3.0 * knu * knu) * gg;
-            rec[28 + q] = rsqrt(4.0 / (kDT * kDT) + y) * (1.0 / kRHO);
-            s_t1 += y * rsqrt(y) * itr;  // tauC enters the block only through its sum over the quadrature points
+        // (b) phase 1: one lane per (patch, tet); the records were requested one patch ago
+        if (t < nt && !(dbg & 2)) {
+            if (!EARLY) slot_load_records(nodep, nd, r);
+            slot_tet_record(r, s_tet + t * SP_RS);
         }
-        rec[32] = s_t1;
-        rec[33] = detJ;
-    }
-    __syncthreads();
-    if (dbg & 1) return;
+        __syncthreads();
+        // (c) hop 3 for the next patch: its node records fly during phase 2
+        if (EARLY && has_next && t < hn.y) slot_load_records(nodep, ndn, r);
 
-    // ---- phase 2: one lane quad per slot -------------------------------------------------------------------------
-    const int j = t & 3;
-    const bool hi2 = (j >> 1) != 0, hi1 = (j & 1) != 0;
-    for (int sq = t >> 2; sq < ns; sq += SBLK / 4) {
-        const int cb0 = s_coff[sq], cb1 = s_coff[sq + 1];
-        const long long nz = s_nz[sq];
-        double acc[16];
+        // ---- phase 2: one lane quad per slot ---------------------------------------------------------------------
+        if (!(dbg & 1)) {
+            const int* s_coff = reinterpret_cast<const int*>(s_lists + buf * lbytes);
+            const int* s_nz = s_coff + max_slots + 1;
+            const unsigned short* s_desc = reinterpret_cast<const unsigned short*>(s_lists + buf * lbytes + desc_off);
+            const int j = t & 3;
+            const bool hi2 = (j >> 1) != 0, hi1 = (j & 1) != 0;
+            for (int sq = t >> 2; sq < ns; sq += SBLK / 4) {
+                const int cb0 = s_coff[sq], cb1 = s_coff[sq + 1];
+                const long long nz = s_nz[sq];
+                double acc[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-        for (int c = cb0 + j; c < cb1; c += 4) {
-            const int d = s_desc[c];
-            const int aa = (d >> 2) & 3, bb = d & 3;
-            const double* rec = s_tet + (d >> 4) * SP_RS;
-            double ga[3], gb[3], t0q[4], ca[4], cb[4];
+                for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+                int c = cb0 + j;
+                int d = c < cb1 ? s_desc[c] : 0;
+                while (c < cb1) {
+                    const int dn = c + 4 < cb1 ? s_desc[c + 4] : 0;  // the next descriptor is fetched before this one is used
+                    const int aa = (d >> 2) & 3, bb = d & 3;
+                    const double* rec = s_tet + (d >> 4) * SP_RS;
+                    double ga[3], gb[3], t0q[4], ca[4], cb[4];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                ga[k] = rec[aa * 3 + k];
-                gb[k] = rec[bb * 3 + k];
+                    for (int k = 0; k < 3; ++k) {
+                        ga[k] = rec[aa * 3 + k];
+                        gb[k] = rec[bb * 3 + k];
+                    }
+                    const d2a* r2 = reinterpret_cast<const d2a*>(rec);
+                    const d2a ca01 = r2[6 + aa * 2], ca23 = r2[7 + aa * 2], cb01 = r2[6 + bb * 2], cb23 = r2[7 + bb * 2];
+                    const d2a ta01 = r2[14], ta23 = r2[15], sc = r2[16];
+                    ca[0] = ca01.x; ca[1] = ca01.y; ca[2] = ca23.x; ca[3] = ca23.y;
+                    cb[0] = cb01.x; cb[1] = cb01.y; cb[2] = cb23.x; cb[3] = cb23.y;
+                    t0q[0] = ta01.x; t0q[1] = ta01.y; t0q[2] = ta23.x; t0q[3] = ta23.y;
+                    if (PROBE && (dbg & 4)) {
+                        acc[0] += ga[0] + gb[1] + ca[2] + cb[3] + t0q[0] + sc.x + sc.y;
+                    } else {
+                        double Bk[16];
+                        lhs_block_eval_s(aa, bb, ga, gb, sc.y, t0q, sc.x, ca, cb, Bk);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[i] += Bk[i];
+                    }
+                    d = dn;
+                    c += 4;
+                }
+                // reduce-scatter inside the quad: lane j ends up with entries {2j, 2j+1, 8+2j, 9+2j} summed over the 4 lanes
+                double r8[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    r8[i] = (hi2 ? acc[i + 4] : acc[i]) + dpp_quad<0x4E>(hi2 ? acc[i] : acc[i + 4]);
+                    r8[4 + i] = (hi2 ? acc[i + 12] : acc[i + 8]) + dpp_quad<0x4E>(hi2 ? acc[i + 8] : acc[i + 12]);
+                }
+                double2 e0, e1;
+                e0.x = (hi1 ? r8[2] : r8[0]) + dpp_quad<0xB1>(hi1 ? r8[0] : r8[2]);
+                e0.y = (hi1 ? r8[3] : r8[1]) + dpp_quad<0xB1>(hi1 ? r8[1] : r8[3]);
+                e1.x = (hi1 ? r8[6] : r8[4]) + dpp_quad<0xB1>(hi1 ? r8[4] : r8[6]);
+                e1.y = (hi1 ? r8[7] : r8[5]) + dpp_quad<0xB1>(hi1 ? r8[5] : r8[7]);
+                if (PROBE && (dbg & 8)) {
+                    if (e0.x == 1.2345e300) val[nz] = e0.x + e0.y + e1.x + e1.y;
+                    continue;
+                }
+                double2* dst = reinterpret_cast<double2*>(val + nz * 16) + j;
+                if (!BETA0) {
+                    const double2 o0 = dst[0], o1 = dst[4];
+                    e0.x += beta * o0.x; e0.y += beta * o0.y;
+                    e1.x += beta * o1.x; e1.y += beta * o1.y;
+                }
+                dst[0] = e0;
+                dst[4] = e1;
             }
-            const d2a* r2 = reinterpret_cast<const d2a*>(rec);
-            const d2a ca01 = r2[6 + aa * 2], ca23 = r2[7 + aa * 2], cb01 = r2[6 + bb * 2], cb23 = r2[7 + bb * 2];
-            const d2a ta01 = r2[14], ta23 = r2[15], sc = r2[16];
-            ca[0] = ca01.x; ca[1] = ca01.y; ca[2] = ca23.x; ca[3] = ca23.y;
-            cb[0] = cb01.x; cb[1] = cb01.y; cb[2] = cb23.x; cb[3] = cb23.y;
-            t0q[0] = ta01.x; t0q[1] = ta01.y; t0q[2] = ta23.x; t0q[3] = ta23.y;
-            if (PROBE && (dbg & 4)) {
-                acc[0] += ga[0] + gb[1] + ca[2] + cb[3] + t0q[0] + sc.x + sc.y;
-                continue;
-            }
-            double Bk[16];
-            lhs_block_eval_s(aa, bb, ga, gb, sc.y, t0q, sc.x, ca, cb, Bk);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] += Bk[i];
         }
-        // reduce-scatter inside the quad: lane j ends up with entries {2j, 2j+1, 8+2j, 9+2j} summed over the 4 lanes
-        double r8[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            r8[i] = (hi2 ? acc[i + 4] : acc[i]) + dpp_quad<0x4E>(hi2 ? acc[i] : acc[i + 4]);
-            r8[4 + i] = (hi2 ? acc[i + 12] : acc[i + 8]) + dpp_quad<0x4E>(hi2 ? acc[i + 8] : acc[i + 12]);
+        if (!has_next) break;
+        nd = ndn;
+        // (e) the lists of the next patch go into the other buffer (read after the barrier that follows its phase 1)
+        {
+            char* nb = s_lists + (buf ^ 1) * lbytes;
+            int* lc = reinterpret_cast<int*>(nb);
+            int* lz = lc + max_slots + 1;
+            uint2* ld = reinterpret_cast<uint2*>(nb + desc_off);
+            if (t <= hn.w) lc[t] = n_c;
+            if (t < hn.w) lz[t] = n_z;
+            const int nq = (hn2.y + 3) >> 2;
+            if (t < nq) ld[t] = n_d0;
+            if (t + SBLK < nq) ld[t + SBLK] = n_d1;
         }
-        double2 e0, e1;
-        e0.x = (hi1 ? r8[2] : r8[0]) + dpp_quad<0xB1>(hi1 ? r8[0] : r8[2]);
-        e0.y = (hi1 ? r8[3] : r8[1]) + dpp_quad<0xB1>(hi1 ? r8[1] : r8[3]);
-        e1.x = (hi1 ? r8[6] : r8[4]) + dpp_quad<0xB1>(hi1 ? r8[4] : r8[6]);
-        e1.y = (hi1 ? r8[7] : r8[5]) + dpp_quad<0xB1>(hi1 ? r8[5] : r8[7]);
-        if (PROBE && (dbg & 8)) { if (e0.x == 1.2345e300) val[nz] = e0.x + e0.y + e1.x + e1.y; continue; }
-        double2* dst = reinterpret_cast<double2*>(val + nz * 16) + j;
-        if (!BETA0) {
-            const double2 o0 = dst[0], o1 = dst[4];
-            e0.x += beta * o0.x; e0.y += beta * o0.y;
-            e1.x += beta * o1.x; e1.y += beta * o1.y;
-        }
-        dst[0] = e0;
-        dst[4] = e1;
+        __syncthreads();  // every wave is done with the tet records of this patch
+        h = hn; h2 = hn2; hn = hnn; hn2 = hnn2;
+        p = pn; pn = pnn;
+        buf ^= 1;
     }
 }
 
@@ -250,23 +332,46 @@ void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const I* ptet_ien, 
                                const unsigned short* desc, const T* nodep, T* val, T beta, I max_tets, I max_slots,
                                I max_contrib, void* stream) {
     if (npatch <= 0) return;
+    if (max_tets > SBLK || max_slots > SBLK - 1 || max_contrib > 8 * SBLK) {
+        fprintf(stderr, "dfl_assemble_tet_lhs_slot: patch limits exceeded (tets %d <= %d, slots %d <= %d, contributions %d <= %d)\n",
+                (int)max_tets, SBLK, (int)max_slots, SBLK - 1, (int)max_contrib, 8 * SBLK);
+        abort();
+    }
     const size_t lds = slot_lds_bytes(max_tets, max_slots, max_contrib);
+    // persistent grid: as many workgroups as the device keeps resident at this LDS size (re-derived when the size changes)
     static size_t lds_set = 0;
-    if (lds > lds_set) {
-        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static int resident = 0, resident_early = 0;
+    if (lds != lds_set) {
+        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0, cus = 0, occ = 0;
+        DFL_GUARD(hipGetDevice(&dev));
+        DFL_GUARD(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        DFL_GUARD(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)tet_lhs_slot_kernel<true, false, false>, SBLK, lds));
+        if (occ < 1) occ = 1;
+        if (cus < 8) cus = 8;
+        resident = cus * occ;
+        DFL_GUARD(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)tet_lhs_slot_kernel<true, true, true>, SBLK, lds));
+        resident_early = cus * (occ < 1 ? 1 : occ);
         lds_set = lds;
     }
-    const int grid = 8 * ((npatch + 7) / 8);
+    int grid = resident / 8 * 8;
+    const int need = 8 * ((npatch + 7) / 8);
+    if (grid > need) grid = need;
     const int4* h4 = reinterpret_cast<const int4*>(hdr);
     const int4* pi4 = reinterpret_cast<const int4*>(ptet_ien);
-    if (g_patch_dbg)
-        tet_lhs_slot_kernel<true, true><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, g_patch_dbg);
+    if (g_patch_dbg & 16) {  // developer A/B: early record prefetch (2 waves per SIMD), grid for that occupancy
+        int g2 = resident_early / 8 * 8;
+        if (g2 > need) g2 = need;
+        tet_lhs_slot_kernel<true, true, true><<<g2, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, max_contrib, g_patch_dbg);
+    } else if (g_patch_dbg)
+        tet_lhs_slot_kernel<true, true, false><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, max_contrib, g_patch_dbg);
     else if (beta == 0.0)
-        tet_lhs_slot_kernel<true, false><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, 0);
+        tet_lhs_slot_kernel<true, false, false><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, max_contrib, 0);
     else
-        tet_lhs_slot_kernel<false, false><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, 0);
+        tet_lhs_slot_kernel<false, false, false><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, max_contrib, 0);
     DFL_LAUNCH_CHECK();
 }
 

@@ -374,6 +374,85 @@ __global__ __launch_bounds__(256) void scatter_idx_kernel(I n, const I* __restri
     if (i < n) x[idx[i]] = in[i];
 }
 
+
+// ---- generalized-alpha state algebra of the Newton driver, fused (src/main.c:107-118, 242-253, 535-565) -----------------
+// One thread per node.  The reference runs this as memset + 6 cublasDaxpy/Dcopy passes over 6N-vectors; the arithmetic
+// per entry is kept (zero + a*x as a product, every axpy as one fused multiply-add, in the reference's order):
+//   dwgalpha = f1_0 * dwgold + f1_1 * dwg           (pressure slot: dwgalpha = dwg, not alpha-interpolated)
+//   wgalpha  = wgold + f2_0 * dwgold + f2_1 * dwg   (pressure slot: 0)
+// nodep != NULL: the packed gather record of the node (pack_nodes_kernel layout) is written in the same pass.
+__global__ __launch_bounds__(BLK) void alpha_states_kernel(I N, const T* __restrict__ wgold, const T* __restrict__ dwgold,
+                                                          const T* __restrict__ dwg, T f1_0, T f1_1, T f2_0, T f2_1,
+                                                          const T* __restrict__ xg, T* __restrict__ wga, T* __restrict__ dwga,
+                                                          T* __restrict__ nodep) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= N) return;
+    const long long idx[6] = {3 * i, 3 * i + 1, 3 * i + 2, 3LL * N + i, 4LL * N + i, 5LL * N + i};
+    double w[6], d[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double o = wgold[idx[k]], d0 = dwgold[idx[k]], d1 = dwg[idx[k]];
+        if (k == 3) { d[k] = d1; w[k] = 0.0; }
+        else {
+            d[k] = fma(f1_1, d1, f1_0 * d0);
+            w[k] = fma(f2_1, d1, fma(f2_0, d0, o));
+        }
+        wga[idx[k]] = w[k];
+        dwga[idx[k]] = d[k];
+    }
+    if (nodep) {  // x[3] u[3] phi T du[3] p(rate vector, Q9) dphi dT pad pad
+        double2* o = reinterpret_cast<double2*>(nodep + i * 16);
+        const double x0 = xg[3 * i], x1 = xg[3 * i + 1], x2 = xg[3 * i + 2];
+        o[0] = make_double2(x0, x1);
+        o[1] = make_double2(x2, w[0]);
+        o[2] = make_double2(w[1], w[2]);
+        o[3] = make_double2(w[4], w[5]);
+        o[4] = make_double2(d[0], d[1]);
+        o[5] = make_double2(d[2], d[3]);
+        o[6] = make_double2(d[4], d[5]);
+        o[7] = make_double2(0.0, 0.0);
+    }
+}
+
+// predictor (main.c:544-546): dwg *= fac on the velocity and phi / T slots (the pressure slot is left alone)
+__global__ __launch_bounds__(BLK) void alpha_predict_kernel(I N, T fac, T* __restrict__ dwg) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= 6LL * N) return;
+    if (i >= 3LL * N && i < 4LL * N) return;
+    dwg[i] *= fac;
+}
+// corrector (main.c:556-565): wgold += c0 * dwgold + c1 * dwg (not the pressure slot), then dwgold = dwg (all slots)
+__global__ __launch_bounds__(BLK) void alpha_correct_kernel(I N, T c0, T c1, T* __restrict__ wgold, T* __restrict__ dwgold,
+                                                           const T* __restrict__ dwg) {
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i >= 6LL * N) return;
+    const double d1 = dwg[i];
+    if (!(i >= 3LL * N && i < 4LL * N)) wgold[i] = fma(c1, d1, fma(c0, dwgold[i], wgold[i]));
+    dwgold[i] = d1;
+}
+
+// four segment sums of squares in one pass (Newton norms of u, p, phi, T; main.c:125-130): grid (blocks, 4)
+__global__ __launch_bounds__(BLK) void norms4_stage1(I N, const T* __restrict__ F, T* __restrict__ part, int nblk) {
+    __shared__ double lds[4];
+    const int seg = blockIdx.y;
+    const long long begin = seg == 0 ? 0 : (2LL + seg) * N, len = seg == 0 ? 3LL * N : N;
+    double acc = 0.0;
+    for (long long k = (long long)blockIdx.x * BLK + threadIdx.x; k < len; k += (long long)nblk * BLK) {
+        const double v = F[begin + k];
+        acc += v * v;
+    }
+    const double r = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) part[seg * nblk + blockIdx.x] = r;
+}
+template <bool SQRT>
+__global__ __launch_bounds__(BLK) void norms4_stage2(int nblk, const T* __restrict__ part, T* __restrict__ out) {
+    __shared__ double lds[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += BLK) acc += part[blockIdx.x * nblk + i];
+    const double r = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) out[blockIdx.x] = SQRT ? sqrt(r) : r;
+}
+
 }  // namespace
 
 extern "C" {
@@ -388,6 +467,34 @@ void dfl_scatter_idx(I n, const I* idx, const T* in, T* x, void* stream) {
     DFL_LAUNCH_CHECK();
 }
 
+
+
+void dfl_alpha_states(I N, const T* wgold, const T* dwgold, const T* dwg, T f1_0, T f1_1, T f2_0, T f2_1, const T* xg, T* wgalpha,
+                      T* dwgalpha, T* nodep, void* stream) {
+    if (N <= 0) return;
+    alpha_states_kernel<<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, wgold, dwgold, dwg, f1_0, f1_1, f2_0, f2_1, xg, wgalpha, dwgalpha, nodep);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_alpha_predict(I N, T fac, T* dwg, void* stream) {
+    if (N <= 0) return;
+    alpha_predict_kernel<<<ceil_div(6LL * N, BLK), BLK, 0, S(stream)>>>(N, fac, dwg);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_alpha_correct(I N, T c0, T c1, T* wgold, T* dwgold, const T* dwg, void* stream) {
+    if (N <= 0) return;
+    alpha_correct_kernel<<<ceil_div(6LL * N, BLK), BLK, 0, S(stream)>>>(N, c0, c1, wgold, dwgold, dwg);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_norms4(I N, const T* F, T* d_out4, int take_sqrt, T* work, void* stream) {
+    if (N <= 0) return;
+    int nblk = ceil_div(3LL * N, BLK * 8);
+    if (nblk < 1) nblk = 1;
+    if (nblk > MAX_PART / 4) nblk = MAX_PART / 4;
+    norms4_stage1<<<dim3(nblk, 4), BLK, 0, S(stream)>>>(N, F, work, nblk);
+    if (take_sqrt) norms4_stage2<true><<<4, BLK, 0, S(stream)>>>(nblk, work, d_out4);
+    else norms4_stage2<false><<<4, BLK, 0, S(stream)>>>(nblk, work, d_out4);
+    DFL_LAUNCH_CHECK();
+}
 
 int dfl_abi_version(void) { return 1; }
 const char* dfl_last_error(void) { return g_err; }

@@ -9,50 +9,124 @@
 //       overlap d = 2R - |xi - xj| > 0,  n = (xi - xj)/|xi - xj|
 //       F_ij = (kn * d - gn * ((vi - vj) . n)) n          acc_i = sum_j F_ij / m
 //   plus the same law against the six walls of the unit box (d = R - distance to wall).
-// Neighbour search: uniform cell list, cell edge >= 2R, particles sorted by cell
-// (stable radix sort => fixed summation order => bitwise reproducible forces).
+// Neighbour search: uniform cell list, cell edge >= 2R, particles sorted by (cell, particle id)
+// (counting sort + per-cell ordering => fixed summation order => bitwise reproducible forces).
 // HBM-bound: (48 read + 24 write) B per particle + 24 B per tested neighbour.
 #include "dfl_common.hpp"
-#include <cstring>
-#include <rocprim/rocprim.hpp>
 
 namespace {
 
 constexpr int BLK = 256;
+constexpr int SCAN_CHUNK = 1024;  // cells per scan block
 
 __device__ __forceinline__ int cell_coord(double x, double inv_cell, int ncell) {
     int c = (int)floor(x * inv_cell);
     return c < 0 ? 0 : (c >= ncell ? ncell - 1 : c);
 }
 
-__global__ void cell_index_kernel(I P, const T* __restrict__ coord, T inv_cell, I ncell, I* __restrict__ cell_id,
-                                  I* __restrict__ order) {
+// The whole sweep is five small dependent launches on the library stream, no allocation, no host round trip:
+//   bin    cell of every particle; count[cell]++ and chunk_sum[cell / 1024]++ (integer atomics: the COUNTS are
+//          deterministic, the returned ranks are not -- the segment sort below removes that freedom)
+//   scan   cell_start = exclusive scan of count (every block adds up the chunk sums before it: one launch), count zeroed
+//   place  order[cell_start[cell] + rank] = particle; chunk sums zeroed for the next sweep
+//   sort   the first particle of every non-empty cell orders the cell's few entries by particle id (=> the neighbour
+//          loops visit particles in a FIXED order: bitwise reproducible forces) and writes the sorted copies of
+//          position / velocity, so that the force kernel streams contiguous runs instead of gathering through order[]
+//   force  one thread per sorted slot over the 9 contiguous 3-cell runs around it
+__global__ __launch_bounds__(BLK) void dem_bin_kernel(I P, const T* __restrict__ coord, T inv_cell, I ncell, I* __restrict__ cell_of,
+                                                     I* __restrict__ rank, I* __restrict__ count, I* __restrict__ chunk_sum) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= P) return;
     const int cx = cell_coord(coord[3 * i], inv_cell, ncell);
     const int cy = cell_coord(coord[3 * i + 1], inv_cell, ncell);
     const int cz = cell_coord(coord[3 * i + 2], inv_cell, ncell);
-    cell_id[i] = cx + ncell * (cy + ncell * cz);
-    order[i] = i;
+    const int c = cx + ncell * (cy + ncell * cz);
+    cell_of[i] = c;
+    rank[i] = atomicAdd(&count[c], 1);
+    atomicAdd(&chunk_sum[c / SCAN_CHUNK], 1);
 }
 
-// cell_start[c] = first sorted slot of cell c, cell_start[ncell3] = P ; empty cells get the next start
-__global__ void cell_bounds_kernel(I P, const I* __restrict__ sorted_cell, I ncell3, I* __restrict__ cell_start) {
+// cell_start[0 .. n] = exclusive scan of count[0 .. n) (cell_start[n] = total); block b owns cells [b*1024, (b+1)*1024)
+__global__ __launch_bounds__(BLK) void dem_scan_kernel(I n, I* __restrict__ count, const I* __restrict__ chunk_sum,
+                                                      I* __restrict__ cell_start) {
+    __shared__ int s_part[BLK];
+    __shared__ int s_base;
+    const int t = threadIdx.x, b = blockIdx.x;
+    int acc = 0;
+    for (int k = t; k < b; k += BLK) acc += chunk_sum[k];
+    s_part[t] = acc;
+    __syncthreads();
+    for (int off = BLK / 2; off > 0; off >>= 1) {
+        if (t < off) s_part[t] += s_part[t + off];
+        __syncthreads();
+    }
+    if (t == 0) s_base = s_part[0];
+    __syncthreads();
+    const int base = s_base;
+    __syncthreads();
+    // 4 consecutive cells per thread
+    const long long c0 = (long long)b * SCAN_CHUNK + 4 * t;
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = (c0 + k < n) ? count[c0 + k] : 0;
+        if (c0 + k < n) count[c0 + k] = 0;  // ready for the next sweep
+    }
+    const int mine = v[0] + v[1] + v[2] + v[3];
+    s_part[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < BLK; off <<= 1) {  // Hillis-Steele inclusive scan of the 256 thread sums
+        const int add = t >= off ? s_part[t - off] : 0;
+        __syncthreads();
+        s_part[t] += add;
+        __syncthreads();
+    }
+    int run = base + s_part[t] - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (c0 + k <= n) cell_start[c0 + k] = run;
+        run += v[k];
+    }
+}
+
+__global__ __launch_bounds__(BLK) void dem_place_kernel(I P, const I* __restrict__ cell_of, const I* __restrict__ rank,
+                                                       const I* __restrict__ cell_start, I* __restrict__ order, I nchunk,
+                                                       I* __restrict__ chunk_sum) {
     const int i = blockIdx.x * BLK + threadIdx.x;
-    if (i > P) return;
-    const int cur = (i < P) ? sorted_cell[i] : ncell3;
-    const int prev = (i > 0) ? sorted_cell[i - 1] : -1;
-    for (int c = prev + 1; c <= cur; ++c) cell_start[c] = i;
+    if (i < nchunk) chunk_sum[i] = 0;
+    if (i >= P) return;
+    order[cell_start[cell_of[i]] + rank[i]] = i;
 }
 
-__global__ __launch_bounds__(BLK) void dem_force_kernel(I P, const T* __restrict__ coord, const T* __restrict__ vel, T R, T mass,
-                                                       T kn, T gn, T inv_cell, I ncell, const I* __restrict__ order,
-                                                       const I* __restrict__ cell_start, T* __restrict__ acc) {
+__global__ __launch_bounds__(BLK) void dem_sort_cells_kernel(I P, const I* __restrict__ cell_of, const I* __restrict__ rank,
+                                                            const I* __restrict__ cell_start, I* __restrict__ order,
+                                                            const T* __restrict__ coord, const T* __restrict__ vel,
+                                                            T* __restrict__ sorted /*[P][6]*/) {
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= P || rank[i] != 0) return;  // one thread per non-empty cell
+    const int c = cell_of[i];
+    const int lo = cell_start[c], hi = cell_start[c + 1];
+    for (int a = lo + 1; a < hi; ++a) {  // insertion sort of a handful of entries
+        const int key = order[a];
+        int b = a - 1;
+        while (b >= lo && order[b] > key) { order[b + 1] = order[b]; --b; }
+        order[b + 1] = key;
+    }
+    for (int a = lo; a < hi; ++a) {
+        const long long j = order[a];
+        T* o = sorted + (long long)a * 6;
+        o[0] = coord[3 * j]; o[1] = coord[3 * j + 1]; o[2] = coord[3 * j + 2];
+        o[3] = vel[3 * j]; o[4] = vel[3 * j + 1]; o[5] = vel[3 * j + 2];
+    }
+}
+
+__global__ __launch_bounds__(BLK) void dem_force_kernel(I P, const T* __restrict__ sorted, T R, T mass, T kn, T gn, T inv_cell,
+                                                       I ncell, const I* __restrict__ order, const I* __restrict__ cell_start,
+                                                       T* __restrict__ acc) {
     const int s = blockIdx.x * BLK + threadIdx.x;
     if (s >= P) return;
-    const int i = order[s];
-    const double xi = coord[3 * i], yi = coord[3 * i + 1], zi = coord[3 * i + 2];
-    const double ui = vel[3 * i], vi = vel[3 * i + 1], wi = vel[3 * i + 2];
+    const T* me = sorted + (long long)s * 6;
+    const double xi = me[0], yi = me[1], zi = me[2], ui = me[3], vi = me[4], wi = me[5];
     const int cx = cell_coord(xi, inv_cell, ncell), cy = cell_coord(yi, inv_cell, ncell), cz = cell_coord(zi, inv_cell, ncell);
     double fx = 0.0, fy = 0.0, fz = 0.0;
     const double d2max = 4.0 * R * R;
@@ -64,16 +138,16 @@ __global__ __launch_bounds__(BLK) void dem_force_kernel(I P, const T* __restrict
             if (y < 0 || y >= ncell) continue;
             const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < ncell ? cx + 1 : ncell - 1;
             const int c0 = x0 + ncell * (y + ncell * z), c1 = x1 + ncell * (y + ncell * z);
-            // the three x-neighbour cells are contiguous in the sorted order
+            // the three x-neighbour cells are one contiguous run of the sorted copies
             for (int t = cell_start[c0]; t < cell_start[c1 + 1]; ++t) {
-                const int j = order[t];
-                if (j == i) continue;
-                const double rx = xi - coord[3 * j], ry = yi - coord[3 * j + 1], rz = zi - coord[3 * j + 2];
+                if (t == s) continue;
+                const T* o = sorted + (long long)t * 6;
+                const double rx = xi - o[0], ry = yi - o[1], rz = zi - o[2];
                 const double d2 = rx * rx + ry * ry + rz * rz;
                 if (d2 >= d2max || d2 == 0.0) continue;
                 const double dist = sqrt(d2), inv = 1.0 / dist;
                 const double nx = rx * inv, ny = ry * inv, nz = rz * inv;
-                const double vn = (ui - vel[3 * j]) * nx + (vi - vel[3 * j + 1]) * ny + (wi - vel[3 * j + 2]) * nz;
+                const double vn = (ui - o[3]) * nx + (vi - o[4]) * ny + (wi - o[5]) * nz;
                 const double f = kn * (2.0 * R - dist) - gn * vn;
                 fx += f * nx; fy += f * ny; fz += f * nz;
             }
@@ -90,6 +164,7 @@ __global__ __launch_bounds__(BLK) void dem_force_kernel(I P, const T* __restrict
         if (hi > 0.0) fw[d] -= kn * hi + gn * v[d];
     }
     const double im = 1.0 / mass;
+    const long long i = order[s];
     acc[3 * i] = (fx + fw[0]) * im;
     acc[3 * i + 1] = (fy + fw[1]) * im;
     acc[3 * i + 2] = (fz + fw[2]) * im;
@@ -108,41 +183,27 @@ __global__ void dem_integrate_kernel(I n3, T dt, T* __restrict__ coord, T* __res
 
 extern "C" {
 
-void dfl_dem_cell_index(I P, const T* coord, T cell, I ncell, I* cell_id, I* order, void* stream) {
+I dfl_dem_num_chunks(I ncell3) { return (I)(((long long)ncell3 + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK); }
+
+// count[ncell3 + 1] and chunk_sum[dfl_dem_num_chunks] must be zero on entry (they are again on return)
+void dfl_dem_build_cells(I P, const T* coord, const T* vel, T cell, I ncell, I* cell_of, I* rank, I* count, I* chunk_sum,
+                         I* cell_start, I* order, T* sorted, void* stream) {
     if (P <= 0) return;
-    cell_index_kernel<<<ceil_div(P, BLK), BLK, 0, S(stream)>>>(P, coord, 1.0 / cell, ncell, cell_id, order);
+    const I ncell3 = ncell * ncell * ncell;
+    const I nchunk = dfl_dem_num_chunks(ncell3);
+    dem_bin_kernel<<<ceil_div(P, BLK), BLK, 0, S(stream)>>>(P, coord, 1.0 / cell, ncell, cell_of, rank, count, chunk_sum);
+    dem_scan_kernel<<<nchunk, BLK, 0, S(stream)>>>(ncell3, count, chunk_sum, cell_start);
+    const int n3 = P > nchunk ? P : nchunk;
+    dem_place_kernel<<<ceil_div(n3, BLK), BLK, 0, S(stream)>>>(P, cell_of, rank, cell_start, order, nchunk, chunk_sum);
+    dem_sort_cells_kernel<<<ceil_div(P, BLK), BLK, 0, S(stream)>>>(P, cell_of, rank, cell_start, order, coord, vel, sorted);
     DFL_LAUNCH_CHECK();
 }
 
-// sorts (cell_id, order) by cell (stable) and builds cell_start[ncell3+1]; synchronises; allocates temp storage
-void dfl_dem_sort_by_cell(I P, I* cell_id, I* order, I ncell3, I* cell_start) {
+void dfl_dem_forces(I P, const T* sorted, T radius, T mass, T kn, T gamma_n, T cell, I ncell, const I* order, const I* cell_start,
+                    T* acc, void* stream) {
     if (P <= 0) return;
-    I *k2 = nullptr, *v2 = nullptr;
-    DFL_GUARD(hipMalloc((void**)&k2, sizeof(I) * (size_t)P));
-    DFL_GUARD(hipMalloc((void**)&v2, sizeof(I) * (size_t)P));
-    int bits = 1;
-    while ((1LL << bits) < (long long)ncell3 + 1 && bits < 31) ++bits;
-    size_t bytes = 0;
-    unsigned int* kin = reinterpret_cast<unsigned int*>(cell_id);
-    unsigned int* kout = reinterpret_cast<unsigned int*>(k2);
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, order, v2, (size_t)P, 0, bits);
-    void* tmp = nullptr;
-    DFL_GUARD(hipMalloc(&tmp, bytes + 16));
-    DFL_GUARD(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, order, v2, (size_t)P, 0, bits));
-    DFL_GUARD(hipMemcpyAsync(cell_id, k2, sizeof(I) * (size_t)P, hipMemcpyDeviceToDevice, 0));
-    DFL_GUARD(hipMemcpyAsync(order, v2, sizeof(I) * (size_t)P, hipMemcpyDeviceToDevice, 0));
-    cell_bounds_kernel<<<ceil_div((long long)P + 1, BLK), BLK>>>(P, cell_id, ncell3, cell_start);
-    DFL_GUARD(hipDeviceSynchronize());
-    DFL_GUARD(hipFree(tmp));
-    DFL_GUARD(hipFree(k2));
-    DFL_GUARD(hipFree(v2));
-}
-
-void dfl_dem_forces(I P, const T* coord, const T* vel, T radius, T mass, T kn, T gamma_n, T cell, I ncell, const I* order,
-                    const I* cell_start, T* acc, void* stream) {
-    if (P <= 0) return;
-    dem_force_kernel<<<ceil_div(P, BLK), BLK, 0, S(stream)>>>(P, coord, vel, radius, mass, kn, gamma_n, 1.0 / cell, ncell, order,
-                                                            cell_start, acc);
+    dem_force_kernel<<<ceil_div(P, BLK), BLK, 0, S(stream)>>>(P, sorted, radius, mass, kn, gamma_n, 1.0 / cell, ncell, order, cell_start,
+                                                            acc);
     DFL_LAUNCH_CHECK();
 }
 

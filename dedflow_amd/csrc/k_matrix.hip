@@ -380,6 +380,137 @@ __global__ __launch_bounds__(BLK) void block_to_submat_kernel(T* const* __restri
     }
 }
 
+
+// (batch slot, a, b) -> element id, row node, column node and the position of (row, col) in the nodal pattern (-1: absent)
+struct ElemEntry { long long iel; I row, start, len, pos; };
+__device__ __forceinline__ ElemEntry elem_entry(long long idx, I nshl, const I* __restrict__ batch_index_ptr,
+                                                const I* __restrict__ ien, const I* __restrict__ rp, const I* __restrict__ ci) {
+    const int n2 = nshl * nshl;
+    const long long slot = idx / n2;
+    ElemEntry e;
+    e.iel = batch_index_ptr ? batch_index_ptr[slot] : slot;
+    const int aa = (int)(idx % n2) / nshl, bb = (int)(idx % nshl);
+    e.row = ien[e.iel * nshl + aa];
+    const I col = ien[e.iel * nshl + bb];
+    e.start = rp[e.row];
+    e.len = rp[e.row + 1] - e.start;
+    I lo = 0, hi = e.len - 1;  // ascending column indices inside a row
+    while (lo < hi) {
+        const I mid = (lo + hi) >> 1;
+        if (ci[e.start + mid] < col) lo = mid + 1; else hi = mid;
+    }
+    e.pos = (e.len > 0 && ci[e.start + lo] == col) ? lo : -1;
+    return e;
+}
+
+// One scalar or row-expanded block CSR matrix over a nodal pattern (the single-matrix case of the kernel above):
+// MatrixCSRAddElemValue[Blocked]BatchedGPU, matrix_impl.h:29-43.  The reference's kernels (matrix_impl.cu:88-208) take
+// the (a, b) pair from the ELEMENT id instead of the thread id and mix two value layouts; this is the behaviour their
+// call sites document (scatter of one br x bc block per (element, a, b) into the layout of csr_impl.cu:24-59).
+__global__ __launch_bounds__(BLK) void csr_elem_blocked_kernel(T* __restrict__ matval, T alpha, I nshl, I batch_size,
+                                                              const I* __restrict__ batch_index_ptr, const I* __restrict__ ien,
+                                                              const I* __restrict__ rp, const I* __restrict__ ci, I br, I bc,
+                                                              const T* __restrict__ val, int lda, int stride, T beta,
+                                                              const I* __restrict__ mask) {
+    const long long idx = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= (long long)batch_size * nshl * nshl) return;
+    if (mask && mask[idx / (nshl * nshl)] == 0) return;
+    const ElemEntry e = elem_entry(idx, nshl, batch_index_ptr, ien, rp, ci);
+    if (e.pos < 0) return;
+    T* m = matval + (long long)e.start * br * bc + (long long)e.pos * bc;
+    const T* b = val + idx * stride;
+    for (I ii = 0; ii < br; ++ii)
+        for (I jj = 0; jj < bc; ++jj) {
+            T* dst = m + (long long)ii * e.len * bc + jj;
+            *dst = alpha * *dst + beta * b[ii * lda + jj];
+        }
+}
+
+// the same scatter straight into the 4x4 block array of a block-mode (u,p) MatrixFS: rows / columns 0..3 of the
+// lda-strided element block, the phi / T part dropped exactly as the reference drops it (NULL sub-matrices)
+__global__ __launch_bounds__(BLK) void bcsr_elem_scatter_kernel(T* __restrict__ block_val, T alpha, I nshl, I batch_size,
+                                                               const I* __restrict__ batch_index_ptr, const I* __restrict__ ien,
+                                                               const I* __restrict__ rp, const I* __restrict__ ci,
+                                                               const T* __restrict__ val, int lda, int stride, T beta,
+                                                               const I* __restrict__ mask) {
+    const long long idx = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= (long long)batch_size * nshl * nshl) return;
+    if (mask && mask[idx / (nshl * nshl)] == 0) return;
+    const ElemEntry e = elem_entry(idx, nshl, batch_index_ptr, ien, rp, ci);
+    if (e.pos < 0) return;
+    T* m = block_val + ((long long)e.start + e.pos) * 16;
+    const T* b = val + idx * stride;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) m[ii * 4 + jj] = alpha * m[ii * 4 + jj] + beta * b[ii * lda + jj];
+}
+
+// MatrixZeroRow on a block-mode (u,p) MatrixFS: `row` holds scalar rows of the velocity block-row (node*3 + comp,
+// dirichlet.c:54-59); rows outside [0, 3N) after the shift are skipped like the reference's pressure block-row call
+// (matrix.c:449-469).  8 lanes per row.
+__global__ __launch_bounds__(BLK) void bcsr_zero_scalar_rows_kernel(I N, const I* rp, const I* ci, T* val, I n, const I* row,
+                                                                   I shift, T diag) {
+    const long long gid = (long long)blockIdx.x * BLK + threadIdx.x;
+    const int i = (int)(gid >> 3), l = threadIdx.x & 7;
+    if (i >= n) return;
+    const long long r = (long long)row[i] + shift;
+    if (r < 0 || r >= 3LL * N) return;
+    const int node = (int)(r / 3), comp = (int)(r - 3LL * node);
+    for (int k = rp[node] + l; k < rp[node + 1]; k += 8) {
+        T* b = val + (long long)k * 16 + comp * 4;
+        const bool isdiag = (ci[k] == node);
+        b[0] = (isdiag && comp == 0) ? diag : 0.0;
+        b[1] = (isdiag && comp == 1) ? diag : 0.0;
+        b[2] = (isdiag && comp == 2) ? diag : 0.0;
+        b[3] = 0.0;
+    }
+}
+
+// MatrixCSRSetValue[Blocked]BatchedGPU (matrix_impl.h:45-62): one (row, col) pair per thread
+__global__ __launch_bounds__(BLK) void csr_set_blocked_kernel(T* __restrict__ matval, T alpha, const I* __restrict__ rp,
+                                                             const I* __restrict__ ci, I batch_size, const I* __restrict__ brow,
+                                                             const I* __restrict__ bcol, I br, I bc, const T* __restrict__ A,
+                                                             T beta, int lda, int stride) {
+    const long long idx = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= batch_size) return;
+    const I row = brow[idx], col = bcol[idx];
+    const I start = rp[row], len = rp[row + 1] - start;
+    I pos = -1;
+    for (I k = 0; k < len; ++k)
+        if (ci[start + k] == col) { pos = k; break; }
+    if (pos < 0) return;
+    T* m = matval + (long long)start * br * bc + (long long)pos * bc;
+    const T* a = A + idx * stride;
+    for (I ii = 0; ii < br; ++ii)
+        for (I jj = 0; jj < bc; ++jj) {
+            T* dst = m + (long long)ii * len * bc + jj;
+            *dst = beta * a[ii * lda + jj] + alpha * *dst;
+        }
+}
+
+// MatrixCSRAddElementLHSGPU (matrix_impl.h:38-43, kernel matrix_impl.cu:209-247): scalar CSR whose rows / columns are
+// node*BS + component; one thread per element adds its (NSHL*BS)^2 dense block.  One batch must be conflict-free.
+__global__ __launch_bounds__(BLK) void csr_add_element_lhs_kernel(T* __restrict__ matval, I nshl, I bs, const I* __restrict__ rp,
+                                                                 const I* __restrict__ ci, I batch_size,
+                                                                 const I* __restrict__ batch_ptr, const I* __restrict__ ien,
+                                                                 const T* __restrict__ val) {
+    const long long idx = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= batch_size) return;
+    const long long iel = batch_ptr ? batch_ptr[idx] : idx;
+    const T* v = val + (long long)nshl * nshl * bs * bs * idx;
+    for (I aa = 0; aa < nshl; ++aa)
+        for (I ii = 0; ii < bs; ++ii) {
+            const I ir = ien[iel * nshl + aa] * bs + ii;
+            for (I bb = 0; bb < nshl; ++bb)
+                for (I jj = 0; jj < bs; ++jj) {
+                    const I ic = ien[iel * nshl + bb] * bs + jj;
+                    for (I j = rp[ir]; j < rp[ir + 1]; ++j)
+                        if (ci[j] == ic) { matval[j] += v[(aa * bs + ii) * bs * nshl + bb * bs + jj]; break; }
+                }
+        }
+}
+
 }  // namespace
 
 extern "C" {
@@ -427,6 +558,55 @@ void SetBlockValueToSubmatGPU(T** matval, T alpha, I n_offset, const I* offset, 
     const long long nthread = (long long)batch_size * nshl * nshl;
     block_to_submat_kernel<<<ceil_div(nthread, BLK), BLK>>>(matval, alpha, n_offset, offset, nshl, batch_size, batch_index_ptr, ien,
                                                             rp, ci, val, lda, stride, beta, mask);
+    DFL_LAUNCH_CHECK();
+}
+
+void MatrixCSRAddElemValueBlockedBatchedGPU(T* matval, T alpha, I batch_size, const I* batch_index_ptr, const I* ien, I nshl,
+                                            I num_row, I num_col, const I* rp, const I* ci, I block_row, I block_col, const T* val,
+                                            int lda, int stride, T beta, const I* mask) {
+    (void)num_row; (void)num_col;
+    if (batch_size <= 0) return;
+    csr_elem_blocked_kernel<<<ceil_div((long long)batch_size * nshl * nshl, BLK), BLK>>>(matval, alpha, nshl, batch_size, batch_index_ptr,
+                                                                                        ien, rp, ci, block_row, block_col, val, lda,
+                                                                                        stride, beta, mask);
+    DFL_LAUNCH_CHECK();
+}
+void MatrixCSRAddElemValueBatchedGPU(T* matval, T alpha, I batch_size, const I* batch_index_ptr, const I* ien, I nshl, I num_row,
+                                     I num_col, const I* rp, const I* ci, const T* val, T beta, const I* mask) {
+    MatrixCSRAddElemValueBlockedBatchedGPU(matval, alpha, batch_size, batch_index_ptr, ien, nshl, num_row, num_col, rp, ci, 1, 1, val, 1,
+                                           1, beta, mask);
+}
+void MatrixCSRSetValueBlockedBatchedGPU(T* matval, T alpha, I csr_num_row, I csr_num_col, const I* rp, const I* ci, I batch_size,
+                                        const I* batch_row_ind, const I* batch_col_ind, I block_row, I block_col, const T* A, T beta,
+                                        int lda, int stride) {
+    (void)csr_num_row; (void)csr_num_col;
+    if (batch_size <= 0) return;
+    csr_set_blocked_kernel<<<ceil_div(batch_size, BLK), BLK>>>(matval, alpha, rp, ci, batch_size, batch_row_ind, batch_col_ind, block_row,
+                                                               block_col, A, beta, lda, stride);
+    DFL_LAUNCH_CHECK();
+}
+void MatrixCSRSetValueBatchedGPU(T* matval, T alpha, I csr_num_row, I csr_num_col, const I* rp, const I* ci, I batch_size,
+                                 const I* batch_row_ind, const I* batch_col_ind, const T* A, T beta) {
+    MatrixCSRSetValueBlockedBatchedGPU(matval, alpha, csr_num_row, csr_num_col, rp, ci, batch_size, batch_row_ind, batch_col_ind, 1, 1, A,
+                                       beta, 1, 1);
+}
+void MatrixCSRAddElementLHSGPU(T* matval, I nshl, I bs, I num_row, const I* rp, I num_col, const I* ci, I batch_size,
+                               const I* batch_ptr, const I* ien, const T* val, int lda) {
+    (void)num_row; (void)num_col; (void)lda;
+    if (batch_size <= 0) return;
+    csr_add_element_lhs_kernel<<<ceil_div(batch_size, BLK), BLK>>>(matval, nshl, bs, rp, ci, batch_size, batch_ptr, ien, val);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_bcsr_add_elem_blocked(T* block_val, T alpha, I nshl, I batch_size, const I* batch_index_ptr, const I* ien, const I* rp,
+                               const I* ci, const T* val, int lda, int stride, T beta, const I* mask, void* stream) {
+    if (batch_size <= 0) return;
+    bcsr_elem_scatter_kernel<<<ceil_div((long long)batch_size * nshl * nshl, BLK), BLK, 0, S(stream)>>>(
+        block_val, alpha, nshl, batch_size, batch_index_ptr, ien, rp, ci, val, lda, stride, beta, mask);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_bcsr_zero_scalar_rows(I N, const I* rp, const I* ci, T* val, I n, const I* row, I shift, T diag, void* stream) {
+    if (n <= 0) return;
+    bcsr_zero_scalar_rows_kernel<<<ceil_div((long long)n * 8, BLK), BLK, 0, S(stream)>>>(N, rp, ci, val, n, row, shift, diag);
     DFL_LAUNCH_CHECK();
 }
 /* kernel-variant selection for A/B measurements (key 0: block-CSR SpMV variant 0..4; 4 = default, XCD-aware row slabs) */

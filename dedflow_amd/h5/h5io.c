@@ -33,6 +33,18 @@ void H5CloseFile(H5FileInfo* f) {
     CdamFreeHost(f, sizeof(H5FileInfo));
 }
 
+/* file access intent, h5util.c:43-57 */
+b32 H5FileIsWritable(H5FileInfo* f) {
+    unsigned intent = 0;
+    H5Fget_intent(f->file_id, &intent);
+    return (intent & (H5F_ACC_RDWR | H5F_ACC_TRUNC)) != 0;
+}
+b32 H5FileIsReadable(H5FileInfo* f) {
+    unsigned intent = 0;
+    H5Fget_intent(f->file_id, &intent);
+    return intent == H5F_ACC_RDONLY || (intent & H5F_ACC_RDWR) != 0;
+}
+
 static int link_exists(hid_t file, const char* path) {
     /* H5Lexists needs every intermediate group to exist */
     char buf[512];
@@ -101,6 +113,63 @@ void H5WriteDatasetf64(H5FileInfo* f, const char* name, index_type len, const f6
 }
 void H5WriteDatasetInd(H5FileInfo* f, const char* name, index_type len, const index_type* data) {
     write_ds(f, name, H5T_STD_I32LE, H5T_NATIVE_INT32, len, data);
+}
+
+/* Mesh3DDataCreateH5, MeshData.c:57-109: host-side coordinates + connectivity of <group> (prism / hex blocks are read when
+ * present, although nothing on the path uses them) */
+Mesh3DData* Mesh3DDataCreateH5(H5FileInfo* f, const char* group) {
+    char p[320];
+    index_type n3 = 0, t4 = 0, np6 = 0, nh8 = 0;
+    ASSERT(f && H5FileIsReadable(f) && "Mesh3DDataCreateH5: Invalid file");
+    ASSERT(group && strlen(group) < 192 && "Mesh3DDateCreateH5: Invalid group name.");
+    snprintf(p, sizeof p, "%s/xg", group); H5GetDatasetSize(f, p, &n3);
+    snprintf(p, sizeof p, "%s/ien/tet", group); H5GetDatasetSize(f, p, &t4);
+    snprintf(p, sizeof p, "%s/ien/prism", group); H5GetDatasetSize(f, p, &np6);
+    snprintf(p, sizeof p, "%s/ien/hex", group); H5GetDatasetSize(f, p, &nh8);
+    ASSERT(n3 % 3 == 0 && t4 % 4 == 0 && np6 % 6 == 0 && nh8 % 8 == 0);
+    Mesh3DData* d = Mesh3DDataCreateHost(n3 / 3, t4 / 4, np6 / 6, nh8 / 8);
+    if (n3) { snprintf(p, sizeof p, "%s/xg", group); H5ReadDatasetf64(f, p, d->xg); }
+    if (t4) { snprintf(p, sizeof p, "%s/ien/tet", group); H5ReadDatasetInd(f, p, d->ien); }
+    if (np6) { snprintf(p, sizeof p, "%s/ien/prism", group); H5ReadDatasetInd(f, p, d->ien + t4); }
+    if (nh8) { snprintf(p, sizeof p, "%s/ien/hex", group); H5ReadDatasetInd(f, p, d->ien + t4 + np6); }
+    return d;
+}
+
+/* ArrayLoad / ArraySave (Array.c:242-261) and ParticleContextLoad / Save (Particle.c:66-103): <group>/{coord,vel,acc} */
+void ArrayLoad(Array* a, H5FileInfo* f, const char* name) {
+    ASSERT(a && f && name && "ArrayLoad: NULL pointer");
+    ASSERT(a->is_host && "ArrayLoad: Array must be host type");
+    ASSERT(H5FileIsReadable(f) && "ArrayLoad: File is not readable");
+    ASSERT(H5DatasetExist(f, name) && "ArrayLoad: Dataset does not exist");
+    index_type len = 0;
+    H5GetDatasetSize(f, name, &len);
+    ASSERT(len == ArrayLen(a) && "ArrayLoad: Array length mismatch");
+    H5ReadDatasetf64(f, name, ArrayData(a));
+}
+void ArraySave(const Array* a, H5FileInfo* f, const char* name) {
+    ASSERT(a && f && name && "ArraySave: NULL pointer");
+    ASSERT(a->is_host && "ArraySave: Array must be host type");
+    ASSERT(H5FileIsWritable(f) && "ArraySave: File is not writable");
+    H5WriteDatasetf64(f, name, ArrayLen(a), ArrayData(a));
+}
+void ParticleContextLoad(ParticleContext* ctx, H5FileInfo* f, const char* group) {
+    char path[256];
+    static const char* part[3] = {"coord", "vel", "acc"};
+    ASSERT(ctx && group && strlen(group) < 192 && "ParticleContextLoad: bad arguments");
+    for (int k = 0; k < 3; ++k) {
+        snprintf(path, sizeof path, "%s/%s", group, part[k]);
+        ArrayLoad(ctx->h_arr[k], f, path);
+        ArrayCopy(ctx->d_arr[k], ctx->h_arr[k], H2D);
+    }
+}
+void ParticleContextSave(const ParticleContext* ctx, H5FileInfo* f, const char* group) {
+    char path[256];
+    static const char* part[3] = {"coord", "vel", "acc"};
+    ASSERT(ctx && group && strlen(group) < 192 && "ParticleContextSave: bad arguments");
+    for (int k = 0; k < 3; ++k) {
+        snprintf(path, sizeof path, "%s/%s", group, part[k]);
+        ArraySave(ctx->h_arr[k], f, path);
+    }
 }
 
 Mesh3D* Mesh3DCreateH5(H5FileInfo* f, const char* group) {

@@ -9,42 +9,43 @@
 
 #define BS (6)
 static b32 g_quiet = FALSE;
-/* patch schedule tunables: tets per patch before the LDS-slot cap applies, and that cap
- * (16 * (cap|1) * 8 B of dynamic LDS per workgroup; 448 -> 57.5 KB -> two workgroups per CU) */
-static index_type g_patch_leaf = 96, g_patch_cap = 448;
+/* process defaults of the per-mesh assembly configuration (copied into every mesh at Mesh3DCreate):
+ *   schedule 2  tets per patch before the LDS-slot cap applies, and that cap (16 * (cap|1) * 8 B of dynamic LDS per
+ *               workgroup; 448 -> 57.5 KB -> two workgroups per CU)
+ *   schedule 3  nodes per patch and the cap on their summed row lengths (LDS slots)
+ *   schedule 4  nodes per patch, nodal nonzeros and tets per patch (one slot offset / one tet per lane of a 256-thread
+ *               workgroup: <= 255 / <= 256); residual: one wave per patch of (tets, nodes) = (16,32), (32,48) or (64,64)
+ *   face group  boundary group whose faces carry the weak-BC terms (the reference hard-codes group 4) */
+static AsmConfig g_asm = {4, 4, 96, 448, 16, 255, 12, 192, 150, 64, 64, 32, 48};
+const AsmConfig* DflAsmDefaults(void) { return &g_asm; }
+void DflSetAssemblySchedule(int mode) { g_asm.sched_mode = mode; }
 void DflSetPatchParameters(index_type leaf, index_type slot_cap) {
-    if (leaf > 0) g_patch_leaf = leaf;
-    if (slot_cap > 0 && slot_cap <= 511) g_patch_cap = slot_cap;
+    if (leaf > 0) g_asm.patch_leaf = leaf;
+    if (slot_cap > 0 && slot_cap <= 511) g_asm.patch_cap = slot_cap;
 }
-/* row-owner patches (schedule 3): nodes per patch and the cap on their summed row lengths (LDS slots) */
-static index_type g_rowpatch_leaf = 16, g_rowpatch_cap = 255;
 void DflSetRowPatchParameters(index_type leaf_nodes, index_type slot_cap) {
-    if (leaf_nodes > 0) g_rowpatch_leaf = leaf_nodes;
-    if (slot_cap > 0 && slot_cap <= 1023) g_rowpatch_cap = slot_cap;
+    if (leaf_nodes > 0) g_asm.rowpatch_leaf = leaf_nodes;
+    if (slot_cap > 0 && slot_cap <= 1023) g_asm.rowpatch_cap = slot_cap;
 }
-/* slot-owner patches (schedule 4): nodes per patch, cap on their summed row lengths, cap on the tets touching them */
-static index_type g_slotpatch_leaf = 16, g_slotpatch_cap = 255, g_slotpatch_tets = 208;
 void DflSetSlotPatchParameters(index_type leaf_nodes, index_type slot_cap, index_type tet_cap) {
-    if (leaf_nodes > 0) g_slotpatch_leaf = leaf_nodes;
-    if (slot_cap > 0) g_slotpatch_cap = slot_cap;
-    if (tet_cap > 0 && (int64_t)tet_cap * dfl_lhs_slot_record_bytes() <= 160 * 1024) g_slotpatch_tets = tet_cap;
+    if (leaf_nodes > 0) g_asm.slot_leaf = leaf_nodes;
+    if (slot_cap > 0) g_asm.slot_cap = slot_cap > 255 ? 255 : slot_cap;
+    if (tet_cap > 0) g_asm.slot_tets = tet_cap > 256 ? 256 : tet_cap;
 }
-static index_type g_rhspatch_leaf = 64, g_rhspatch_nodes = 64;
 void DflSetRhsPatchParameters(index_type leaf_tets, index_type node_cap) {
-    if (leaf_tets > 0 && leaf_tets <= dfl_rhs_patch_max_tets()) g_rhspatch_leaf = leaf_tets;
-    if (node_cap >= 4 && node_cap <= dfl_rhs_patch_max_nodes()) g_rhspatch_nodes = node_cap;
+    if (leaf_tets > 0 && leaf_tets <= dfl_rhs_patch_max_tets()) g_asm.rhspatch_leaf = leaf_tets;
+    if (node_cap >= 4 && node_cap <= dfl_rhs_patch_max_nodes()) g_asm.rhspatch_nodes = node_cap;
 }
-/* schedule 4: one wave per residual patch; supported shapes (tets, nodes): (16,32), (32,48), (64,64) */
-static index_type g_rhswave_tets = 32, g_rhswave_nodes = 48;
 void DflSetRhsWaveParameters(index_type tets, index_type nodes) {
     if ((tets == 16 && nodes == 32) || (tets == 32 && nodes == 48) || (tets == 64 && nodes == 64)) {
-        g_rhswave_tets = tets;
-        g_rhswave_nodes = nodes;
+        g_asm.rhswave_tets = tets;
+        g_asm.rhswave_nodes = nodes;
     }
 }
-/* boundary group whose faces carry the weak-BC terms (the reference hard-codes group 4) */
-static index_type g_face_group = 4;
-void DflSetWeakBCGroup(index_type group) { g_face_group = group; }
+void DflSetWeakBCGroup(index_type group) { g_asm.face_group = group; }
+/* the same two switches for one existing mesh (the schedule before Mesh3DGenerateColorBatch) */
+void DflMeshSetAssemblySchedule(Mesh3D* mesh, int mode) { ((MeshExt*)mesh->ext)->cfg.sched_mode = mode; }
+void DflMeshSetWeakBCGroup(Mesh3D* mesh, index_type group) { ((MeshExt*)mesh->ext)->cfg.face_group = group; }
 void DflSetQuiet(b32 quiet) { g_quiet = quiet; }
 /* node coordinates were modified (moving mesh): drop the per-element geometry cache, rebuilt at the next assembly */
 void DflMeshGeometryChanged(Mesh3D* mesh) {
@@ -52,6 +53,11 @@ void DflMeshGeometryChanged(Mesh3D* mesh) {
     if (!x) return;
     CdamFreeDevice(x->egeo_b, 0);
     x->egeo_b = NULL;
+    if (x->patch) { /* schedule 2 keeps its own copy in patch order */
+        CdamFreeDevice(x->patch->d_egeo, 0);
+        x->patch->d_egeo = NULL;
+    }
+    /* schedule 4 and the residual kernels recompute the geometry from the node records; the face lists hold no geometry */
 }
 b32 DflQuiet(void) { return g_quiet; }
 
@@ -75,6 +81,16 @@ static void ensure_nzmap(Mesh3D* mesh, const CSRAttr* spy) {
     x->nzmap_attr = spy;
 }
 
+f64* DflMeshNodeRecords(Mesh3D* mesh) {
+    MeshExt* x = (MeshExt*)mesh->ext;
+    if (!x->nodep) {
+        const index_type N = Mesh3DNumNode(mesh);
+        x->nodep = (f64*)CdamMallocDevice((ptrdiff_t)N * 16 * SIZE_OF(f64));
+        x->Fp = (f64*)CdamMallocDevice((ptrdiff_t)N * 8 * SIZE_OF(f64));
+    }
+    return x->nodep;
+}
+
 void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J) {
     DflAssembleSystemTetBeta(mesh, wgalpha_dptr, dwgalpha_dptr, F, J, 1.0);
 }
@@ -91,18 +107,15 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
     const CSRAttr* spy = NULL;
     if (J) {
         spy = block_pattern(J, &val);
-        if (DflAssemblyScheduleMode() < 2) ensure_nzmap(mesh, spy);
+        if (x->cfg.sched_mode < 2) ensure_nzmap(mesh, spy);
     }
     /* packed gather records (one line per node) and packed residual accumulator */
-    if (!x->nodep) {
-        x->nodep = (f64*)CdamMallocDevice((ptrdiff_t)N * 16 * SIZE_OF(f64));
-        x->Fp = (f64*)CdamMallocDevice((ptrdiff_t)N * 8 * SIZE_OF(f64));
-    }
-    dfl_pack_nodes(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, x->nodep, s);
-    const b32 patch_lhs = J && DflAssemblyScheduleMode() == 2;
-    const b32 rowpatch_lhs = J && DflAssemblyScheduleMode() == 3;
-    const b32 slot_lhs = J && DflAssemblyScheduleMode() == 4;
-    const b32 patch_rhs = F && DflAssemblyScheduleMode() >= 2;
+    DflMeshNodeRecords(mesh);
+    if (!x->nodep_current) dfl_pack_nodes(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, x->nodep, s);
+    const b32 patch_lhs = J && x->cfg.sched_mode == 2;
+    const b32 rowpatch_lhs = J && x->cfg.sched_mode == 3;
+    const b32 slot_lhs = J && x->cfg.sched_mode == 4;
+    const b32 patch_rhs = F && x->cfg.sched_mode >= 2;
     if (J && !slot_lhs && !x->egeo_b) { /* geometry cache in schedule order (static mesh), built once; the LHS kernels read it */
         x->egeo_b = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
         dfl_elem_geometry(mesh->num_tet, x->ien_b, dev->xg, x->egeo_b, s);
@@ -124,8 +137,8 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
             DflFreePatchSchedule(x->patch);
             x->patch = NULL;
         }
-        if (!x->patch) {
-            x->patch = DflBuildPatchSchedule(mesh, spy, g_patch_leaf, g_patch_cap);
+        if (!x->patch) x->patch = DflBuildPatchSchedule(mesh, spy, x->cfg.patch_leaf, x->cfg.patch_cap);
+        if (!x->patch->d_egeo) {
             x->patch->d_egeo = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
             dfl_elem_geometry(mesh->num_tet, x->patch->d_ien, dev->xg, x->patch->d_egeo, s);
         }
@@ -143,7 +156,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
             x->rowpatch = NULL;
         }
         if (!x->rowpatch) {
-            x->rowpatch = DflBuildRowPatchSchedule(mesh, spy, g_rowpatch_leaf, g_rowpatch_cap);
+            x->rowpatch = DflBuildRowPatchSchedule(mesh, spy, x->cfg.rowpatch_leaf, x->cfg.rowpatch_cap);
         }
         const RowPatchSched* rs = x->rowpatch;
         DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_rowpatch(rs->num_patch, rs->d_ioff, rs->d_soff, rs->d_item_ea, rs->d_item_slot,
@@ -155,20 +168,20 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
             DflFreeSlotPatchSchedule(x->slotpatch);
             x->slotpatch = NULL;
         }
-        if (!x->slotpatch) x->slotpatch = DflBuildSlotPatchSchedule(mesh, spy, g_slotpatch_leaf, g_slotpatch_cap, g_slotpatch_tets);
+        if (!x->slotpatch) x->slotpatch = DflBuildSlotPatchSchedule(mesh, spy, x->cfg.slot_leaf, x->cfg.slot_cap, x->cfg.slot_tets);
         const SlotPatchSched* ss = x->slotpatch;
         DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_slot(ss->num_patch, ss->d_hdr, ss->d_ptet_ien, ss->d_slot_nz, ss->d_coff,
                                                              ss->d_desc, x->nodep, val, beta_J, ss->max_tets, ss->max_slots, ss->max_contrib, s));
     }
     if (patch_rhs) { /* schedules 2, 3, 4: patch-staged residual, two launches, fixed summation order (host/patch.c) */
-        const b32 wave = DflAssemblyScheduleMode() >= 4; /* schedule 4: one wave per patch, padded layout */
+        const b32 wave = x->cfg.sched_mode >= 4; /* schedule 4: one wave per patch, padded layout */
         if (x->rhspatch && (x->rhspatch->pad_tets > 0) != wave) {
             DflFreeRhsPatchSchedule(x->rhspatch);
             x->rhspatch = NULL;
         }
         if (!x->rhspatch)
-            x->rhspatch = wave ? DflBuildRhsPatchSchedule(mesh, g_rhswave_tets, g_rhswave_nodes, g_rhswave_tets, g_rhswave_nodes)
-                               : DflBuildRhsPatchSchedule(mesh, g_rhspatch_leaf, g_rhspatch_nodes, 0, 0);
+            x->rhspatch = wave ? DflBuildRhsPatchSchedule(mesh, x->cfg.rhswave_tets, x->cfg.rhswave_nodes, x->cfg.rhswave_tets, x->cfg.rhswave_nodes)
+                               : DflBuildRhsPatchSchedule(mesh, x->cfg.rhspatch_leaf, x->cfg.rhspatch_nodes, 0, 0);
         const RhsPatchSched* rp = x->rhspatch;
         int slot = DflProfileBegin(DFL_TAG_ASM_RHS);
         if (wave)
@@ -185,7 +198,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
 }
 
 void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J) {
-    const index_type group = g_face_group; /* 4 in the reference, hard-coded at assemble.cu:1826-1828 */
+    const index_type group = ((MeshExt*)mesh->ext)->cfg.face_group; /* 4 in the reference, hard-coded at assemble.cu:1826-1828 */
     const Mesh3DData* dev = Mesh3DDevice(mesh);
     const index_type N = Mesh3DNumNode(mesh);
     hipStream_t s = DflStream();
@@ -208,16 +221,24 @@ void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, 
 }
 
 void AssembleSystem(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, Dirichlet** bcs, index_type nbc) {
+    DflAssembleSystemPrepacked(mesh, wgalpha, dwgalpha, F, J, bcs, nbc, FALSE);
+}
+
+void DflAssembleSystemPrepacked(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, Dirichlet** bcs, index_type nbc,
+                                b32 prepacked) {
     index_type num_node = Mesh3DNumNode(mesh);
+    MeshExt* x = (MeshExt*)mesh->ext;
+    x->nodep_current = prepacked && x->nodep != NULL;
     hipStream_t s = DflStream();
     if (F) HIPGUARD(hipMemsetAsync(F, 0, (size_t)num_node * sizeof(f64) * BS, s));
     /* schedule 3 writes every row of J exactly once: the zero pass folds into that write */
-    const b32 overwrite = J && DflAssemblyScheduleMode() >= 3 && Mesh3DNumTet(mesh) && MatrixFSBlockValues(J);
+    const b32 overwrite = J && x->cfg.sched_mode >= 3 && Mesh3DNumTet(mesh) && MatrixFSBlockValues(J);
     if (J && !overwrite) MatrixZero(J);
     if (Mesh3DNumTet(mesh)) {
         DflAssembleSystemTetBeta(mesh, wgalpha, dwgalpha, F, J, overwrite ? 0.0 : 1.0);
         AssembleSystemTetFace(mesh, wgalpha, dwgalpha, F, J);
     }
+    x->nodep_current = FALSE;
     if (F) HIPGUARD(hipMemsetAsync(F + 4 * (size_t)num_node, 0, (size_t)num_node * sizeof(f64) * 2, s)); /* main.c:63-66 */
     for (index_type ibc = 0; ibc < nbc; ++ibc) {
         if (F) DirichletApplyVec(bcs[ibc], F);

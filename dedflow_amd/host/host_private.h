@@ -66,7 +66,25 @@ typedef struct SlotPatchSched {
 SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap, index_type tet_cap);
 void DflFreeSlotPatchSchedule(SlotPatchSched* ps);
 
+/* Assembly configuration of ONE mesh: a copy of the process defaults (the DflSet* setters of include/dedflow.h) taken
+ * at Mesh3DCreate, so that two meshes with different schedules / face groups / patch shapes coexist in one process. */
+typedef struct AsmConfig {
+    int sched_mode;              /* 0 reference colors, 1 compact colors, 2 tet patches, 3 row-owner patches, 4 slot-owner (default) */
+    index_type face_group;       /* boundary group of the weak-BC faces (4 in the reference, assemble.cu:1826-1828) */
+    index_type patch_leaf, patch_cap;           /* schedule 2: tets per patch, LDS block slots */
+    index_type rowpatch_leaf, rowpatch_cap;     /* schedule 3: nodes per patch, LDS block slots */
+    index_type slot_leaf, slot_cap, slot_tets;  /* schedule 4: nodes per patch, nodal nonzeros, tets touching the patch */
+    index_type rhspatch_leaf, rhspatch_nodes;   /* schedules 2, 3: residual patches */
+    index_type rhswave_tets, rhswave_nodes;     /* schedule 4: one wave per residual patch */
+} AsmConfig;
+const AsmConfig* DflAsmDefaults(void);
+struct FlowWork;
+void DflFreeFlowWork(struct FlowWork* fw);
+
 typedef struct MeshExt {
+    AsmConfig cfg;                 /* assembly configuration of this mesh */
+    struct FlowWork* flow;         /* alpha-level state vectors + norm scratch of SolveFlowSystem (host/driver.c) */
+    b32 nodep_current;             /* the packed node records already hold the states the next AssembleSystem is given */
     index_type* ien_b;             /* device [T][4], elements in execution-schedule order */
     index_type sched_num;          /* number of conflict-free launches of the execution schedule */
     index_type* sched_offset;      /* host [sched_num+1] */
@@ -94,8 +112,7 @@ typedef struct MeshExt {
 void DflMeshPrepareFaces(Mesh3D* mesh, index_type group);
 void DflMeshPrepareFaceNonzeros(Mesh3D* mesh, index_type group, const CSRAttr* spy);
 void DflMeshFreeFaceLists(struct MeshExt* x);
-int DflAssemblyScheduleMode(void);
-/* AssembleSystemTet with J = beta_J * J + contributions (beta_J = 0 only takes effect in schedule 3) */
+/* AssembleSystemTet with J = beta_J * J + contributions (beta_J = 0 only takes effect in schedules 3 and 4) */
 void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, f64 beta_J);
 b32 DflQuiet(void);
 
@@ -108,6 +125,11 @@ void DflProfileEnd(int slot);
 int DflProfileCollect(int tag, double* total_ms, double* min_ms);
 #define DFL_TIMED(tag, call) do { int _s = DflProfileBegin(tag); call; DflProfileEnd(_s); } while (0)
 
+/* AssembleSystem for the Newton driver: `prepacked` = the packed node records were just written from these very states
+ * by the fused alpha-state kernel (host/driver.c), so the pack launch is skipped */
+void DflAssembleSystemPrepacked(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, Dirichlet** bcs, index_type nbc,
+                                b32 prepacked);
+f64* DflMeshNodeRecords(Mesh3D* mesh); /* [N][16] packed gather records, allocated on first use */
 /* driver.c */
 index_type SolveFlowSystem(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* J, f64* F, f64* dx, Krylov* ksp,
                            Dirichlet** bcs, index_type nbc, index_type maxit, f64* rnorm_out, f64* rnorm_init_out);

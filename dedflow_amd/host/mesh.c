@@ -55,6 +55,7 @@ Mesh3D* Mesh3DCreate(index_type nn, index_type nt, index_type np, index_type nh)
     MeshExt* x = (MeshExt*)CdamMallocHost(SIZE_OF(MeshExt));
     memset(x, 0, sizeof *x);
     x->face_group = -1;
+    x->cfg = *DflAsmDefaults();
     m->ext = x;
     return m;
 }
@@ -95,6 +96,7 @@ void Mesh3DDestroy(Mesh3D* m) {
         DflFreeRowPatchSchedule(x->rowpatch);
         DflFreeSlotPatchSchedule(x->slotpatch);
         DflFreeRhsPatchSchedule(x->rhspatch);
+        DflFreeFlowWork(x->flow);
         CdamFreeDevice(x->egeo_b, 0);
         if (x->h_sched_elem) CdamFreeHost(x->h_sched_elem, 0);
         CdamFreeDevice(x->nodep, 0);
@@ -163,14 +165,11 @@ void Mesh3DColor(Mesh3D* mesh) {
     mesh->num_color = GetMaxColor(mesh->color, T) + 1;
 }
 
-static int g_sched_mode = 3;
-/* 0: launches follow the reference's JPL color batches one to one (same summation order as
+/* Execution schedule of the assembly kernels (MeshExt.cfg.sched_mode, include/dedflow.h: DflSetAssemblySchedule):
+ * 0: launches follow the reference's JPL color batches one to one (same summation order as
  *    the reference inside every matrix / RHS entry);
  * 1: compact schedule below.  Results differ from mode 0 by summation order only;
- * 2: RHS as 1, Jacobian by tet patches (patch.c);
- * 3: (default) RHS as 1, Jacobian by row-owner node patches (rowpatch.c). */
-void DflSetAssemblySchedule(int mode) { g_sched_mode = mode; }
-int DflAssemblyScheduleMode(void) { return g_sched_mode; }
+ * 2-4: patch schedules (patch.c, rowpatch.c, slotpatch.c), built on first use by host/assemble.c. */
 
 /* JPL colors one independent set of local maxima per round, i.e. ~140 colors of ~T/140 tets
  * for a tet mesh whose conflict graph needs ~30.  A 77k-tet launch is 4.4 waves per SIMD for
@@ -237,7 +236,7 @@ void Mesh3DGenerateColorBatch(Mesh3D* mesh) {
     if (x->sched_offset) CdamFreeHost(x->sched_offset, 0);
     if (x->h_sched_elem) CdamFreeHost(x->h_sched_elem, 0);
     x->h_sched_elem = NULL;
-    if (DflAssemblyScheduleMode() == 0) {
+    if (x->cfg.sched_mode == 0) {
         /* execution schedule == the reference's JPL color batches */
         x->sched_num = nc;
         x->sched_offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (nc + 1));
@@ -420,6 +419,22 @@ CSRAttr* CSRAttrCreateBlock(const CSRAttr* attr, csr_index_type br, csr_index_ty
 void ExpandCSRByBlockSize(const CSRAttr* attr, CSRAttr* new_attr, csr_index_type block_size[2]) {
     dfl_csr_expand(attr->num_row, attr->row_ptr, attr->col_ind, block_size[0], block_size[1], new_attr->row_ptr, new_attr->col_ind,
                    DflStream());
+}
+
+/* csr.c:226-238 */
+index_type CSRAttrLength(CSRAttr* attr, csr_index_type row) {
+    index_type rp[2];
+    HIPGUARD(hipMemcpy(rp, attr->row_ptr + row, 2 * sizeof(index_type), D2H));
+    return rp[1] - rp[0];
+}
+csr_index_type* CSRAttrRow(CSRAttr* attr, csr_index_type row) {
+    index_type start = 0;
+    HIPGUARD(hipMemcpy(&start, attr->row_ptr + row, sizeof(index_type), D2H));
+    return attr->col_ind + start;
+}
+void CSRAttrGetNonzeroIndBatched(const CSRAttr* attr, csr_index_type batch_size, const index_type* row, const index_type* col,
+                                 index_type* ind) {
+    CSRAttrGetNZIndBatchedGPU(attr, batch_size, row, col, ind);
 }
 
 void CSRAttrDestroy(CSRAttr* attr) {

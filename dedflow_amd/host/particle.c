@@ -13,7 +13,10 @@ typedef struct ParticleExt {
     f64 kn, gamma_n, dt;
     f64 cell;
     index_type ncell;
-    index_type *cell_id, *order, *cell_start; /* device */
+    /* persistent workspace of the sweep (device): nothing is allocated, freed or synchronised per sweep */
+    index_type *cell_of, *rank, *order;        /* [P] */
+    index_type *count, *cell_start, *chunk_sum; /* [ncell^3 + 1], [ncell^3 + 1], [chunks] */
+    f64* sorted;                                /* [P][6] position + velocity in (cell, id) order */
     index_type cap_particle, cap_cell;
 } ParticleExt;
 
@@ -45,9 +48,8 @@ void ParticleContextDestroy(ParticleContext* ctx) {
         ArrayDestroy(ctx->d_arr[k]);
     }
     if (x) {
-        CdamFreeDevice(x->cell_id, 0);
-        CdamFreeDevice(x->order, 0);
-        CdamFreeDevice(x->cell_start, 0);
+        CdamFreeDevice(x->cell_of, 0); CdamFreeDevice(x->rank, 0); CdamFreeDevice(x->order, 0); CdamFreeDevice(x->sorted, 0);
+        CdamFreeDevice(x->count, 0); CdamFreeDevice(x->cell_start, 0); CdamFreeDevice(x->chunk_sum, 0);
         CdamFreeHost(x, SIZE_OF(ParticleExt));
     }
     CdamFreeHost(ctx, SIZE_OF(ParticleContext));
@@ -83,31 +85,32 @@ void ParticleContextComputeForces(ParticleContext* ctx) {
     hipStream_t s = DflStream();
     index_type ncell = (index_type)floor(1.0 / (2.0 * R));
     if (ncell < 1) ncell = 1;
-    if (ncell > 1024) ncell = 1024; /* 2^30 cells at most: cell ids stay inside i32 */
+    if (ncell > 256) ncell = 256; /* 2^24 cells at most (the dense cell arrays); larger cells stay valid: edge >= 2R */
     const f64 cell = 1.0 / (f64)ncell; /* >= 2R */
-    const int64_t ncell3 = (int64_t)ncell * ncell * ncell;
+    const index_type ncell3 = ncell * ncell * ncell;
     if (x->cap_particle < P) {
-        CdamFreeDevice(x->cell_id, 0);
-        CdamFreeDevice(x->order, 0);
-        x->cell_id = (index_type*)CdamMallocDevice((ptrdiff_t)P * SIZE_OF(index_type));
+        CdamFreeDevice(x->cell_of, 0); CdamFreeDevice(x->rank, 0); CdamFreeDevice(x->order, 0); CdamFreeDevice(x->sorted, 0);
+        x->cell_of = (index_type*)CdamMallocDevice((ptrdiff_t)P * SIZE_OF(index_type));
+        x->rank = (index_type*)CdamMallocDevice((ptrdiff_t)P * SIZE_OF(index_type));
         x->order = (index_type*)CdamMallocDevice((ptrdiff_t)P * SIZE_OF(index_type));
+        x->sorted = (f64*)CdamMallocDevice((ptrdiff_t)P * 6 * SIZE_OF(f64));
         x->cap_particle = P;
     }
-    if (x->cap_cell < ncell3 + 1) {
-        CdamFreeDevice(x->cell_start, 0);
-        x->cell_start = (index_type*)CdamMallocDevice((ptrdiff_t)(ncell3 + 1) * SIZE_OF(index_type));
-        x->cap_cell = (index_type)(ncell3 + 1);
+    if (x->cap_cell < ncell3 + 1) { /* zero-filled by the allocator; every sweep leaves count / chunk_sum zeroed again */
+        CdamFreeDevice(x->count, 0); CdamFreeDevice(x->cell_start, 0); CdamFreeDevice(x->chunk_sum, 0);
+        x->count = (index_type*)CdamMallocDevice(((ptrdiff_t)ncell3 + 1) * SIZE_OF(index_type));
+        x->cell_start = (index_type*)CdamMallocDevice(((ptrdiff_t)ncell3 + 1) * SIZE_OF(index_type));
+        x->chunk_sum = (index_type*)CdamMallocDevice((ptrdiff_t)dfl_dem_num_chunks(ncell3) * SIZE_OF(index_type));
+        x->cap_cell = ncell3 + 1;
     }
     x->cell = cell;
     x->ncell = ncell;
     const f64* coord = ArrayData(ParticleCTXDeviceCoord(ctx));
     const f64* vel = ArrayData(ParticleCTXDeviceVel(ctx));
     f64* acc = ArrayData(ParticleCTXDeviceAcc(ctx));
-    dfl_dem_cell_index(P, coord, cell, ncell, x->cell_id, x->order, s);
-    HIPGUARD(hipStreamSynchronize(s));
-    dfl_dem_sort_by_cell(P, x->cell_id, x->order, (index_type)ncell3, x->cell_start);
+    dfl_dem_build_cells(P, coord, vel, cell, ncell, x->cell_of, x->rank, x->count, x->chunk_sum, x->cell_start, x->order, x->sorted, s);
     int slot = DflProfileBegin(DFL_TAG_SMALL + 1);
-    dfl_dem_forces(P, coord, vel, R, ParticleMass(ctx), x->kn, x->gamma_n, cell, ncell, x->order, x->cell_start, acc, s);
+    dfl_dem_forces(P, x->sorted, R, ParticleMass(ctx), x->kn, x->gamma_n, cell, ncell, x->order, x->cell_start, acc, s);
     DflProfileEnd(slot);
 }
 

@@ -97,7 +97,9 @@ static void split(Ctx* x, index_type lo, index_type hi) {
     if (n <= x->leaf) {
         int64_t slots = 0;
         for (index_type i = lo; i < hi; ++i) slots += x->rp[x->idx[i] + 1] - x->rp[x->idx[i]];
-        if (n <= 1 || (slots <= x->cap && count_tets(x, lo, hi) <= x->tcap)) { emit(x, lo, hi); return; }
+        int64_t items = 0; /* (tet, owned node) pairs: 4 contributions each, at most 2048 per patch (8 per lane) */
+        for (index_type i = lo; i < hi; ++i) items += x->vp[x->idx[i] + 1] - x->vp[x->idx[i]];
+        if (n <= 1 || (slots <= x->cap && items <= 512 && count_tets(x, lo, hi) <= x->tcap)) { emit(x, lo, hi); return; }
     }
     f64 bl[3] = {1e300, 1e300, 1e300}, bh[3] = {-1e300, -1e300, -1e300};
     for (index_type i = lo; i < hi; ++i)
@@ -136,7 +138,8 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     const index_type* ien = mesh->host->ien;
     const f64* xg = mesh->host->xg;
     ASSERT((int64_t)T * 16 < 2147483647LL && "slot-patch contribution offsets are 32-bit");
-    if (tet_cap > 4095) tet_cap = 4095; /* 12-bit local tet ids in the descriptors */
+    if (tet_cap > 256) tet_cap = 256;   /* one tet per lane in phase 1 (and 12-bit local tet ids in the descriptors) */
+    if (slot_cap > 255) slot_cap = 255; /* one slot offset per lane */
     SlotPatchSched* ps = (SlotPatchSched*)CdamMallocHost(SIZE_OF(SlotPatchSched));
     memset(ps, 0, sizeof *ps);
     ps->attr = spy;

@@ -601,4 +601,8 @@ void KrylovSolve(Krylov* ksp, Matrix* A, f64* x, f64* b) {
     }
     PCSetup(pc);
     ksp->ksp_solve(A, x, b, ksp);
+    KrylovStats* st = &kext(ksp)->stats;
+    st->total_solves++;
+    st->total_converged += st->converged ? 1 : 0;
+    st->total_iterations += st->iterations;
 }

@@ -120,6 +120,7 @@ Mesh3DData* Mesh3DDataCreateHost(index_type num_node, index_type num_tet, index_
 Mesh3DData* Mesh3DDataCreateDevice(index_type num_node, index_type num_tet, index_type num_prism, index_type num_hex);
 void Mesh3DDataDestroy(Mesh3DData* data);
 void Mesh3DDataCopy(Mesh3DData* dst, Mesh3DData* src, MemCopyKind kind);
+Mesh3DData* Mesh3DDataCreateH5(H5FileInfo* h5f, const char* group_name); /* MeshData.c:57-109; in libdedflow_h5.so */
 
 typedef struct Mesh3D {
     index_type num_node, num_tet, num_prism, num_hex;
@@ -167,6 +168,8 @@ color_t GetMaxColor(const color_t* color, index_type num_elem);
 /* ---- HDF5 formats (h5util.h:24-58; implemented in libdedflow_h5.so, dedflow_amd/h5/h5io.c) ----- */
 H5FileInfo* H5OpenFile(const char* filename, const char* mode);
 void H5CloseFile(H5FileInfo* h5file);
+b32 H5FileIsReadable(H5FileInfo* h5file);
+b32 H5FileIsWritable(H5FileInfo* h5file);
 b32 H5DatasetExist(H5FileInfo* h5file, const char* dataset_name);
 void H5GetDatasetSize(H5FileInfo* h5file, const char* dataset_name, index_type* size);
 void H5ReadDatasetf64(H5FileInfo* h5file, const char* dataset_name, f64* data);
@@ -197,6 +200,12 @@ struct CSRAttr {
 CSRAttr* CSRAttrCreate(const Mesh3D* mesh);
 void CSRAttrDestroy(CSRAttr* attr);
 CSRAttr* CSRAttrCreateBlock(const CSRAttr* attr, csr_index_type block_row, csr_index_type block_col);
+/* csr.h:32-36.  The reference reads attr->row_ptr (a device pointer) on the host in the first two; here they copy the
+ * 4 / 8 bytes they need back.  CSRAttrRow returns a DEVICE pointer into col_ind. */
+index_type CSRAttrLength(CSRAttr* attr, csr_index_type row);
+csr_index_type* CSRAttrRow(CSRAttr* attr, csr_index_type row);
+void CSRAttrGetNonzeroIndBatched(const CSRAttr* attr, csr_index_type batch_size, const index_type* row, const index_type* col,
+                                 index_type* ind);
 /* csr_impl.h:6-9 */
 void ExpandCSRByBlockSize(const CSRAttr* attr, CSRAttr* new_attr, csr_index_type block_size[2]);
 void CSRAttrGetNZIndBatchedGPU(const CSRAttr* attr, csr_index_type batch_size, const index_type* row, const index_type* col,
@@ -265,6 +274,7 @@ struct MatrixFS {
     b32 block_mode;        /* the (u,p) 2x2 layout of src/main.c:374-391 was recognised */
     value_type* block_val; /* [nnz1][16] device, 4x4 blocks over spy1x1 */
     index_type owned_rows; /* node rows this rank owns (== spy1x1->num_row on one GPU): SpMV / PC run on these only */
+    b32 reference_layout;  /* MatrixFSUseReferenceLayout: keep the four row-expanded sub-matrix arrays (no block mode) */
 };
 Matrix* MatrixCreateTypeCSR(const CSRAttr* attr, void*);
 Matrix* MatrixCreateTypeFS(index_type n_offset, const index_type* offset, void*);
@@ -278,17 +288,37 @@ void MatrixAMVPBYWithMask(Matrix* A, value_type alpha, value_type* x, value_type
 void MatrixMatVec(Matrix* matrix, value_type* x, value_type* y);
 void MatrixMatVecWithMask(Matrix* matrix, value_type* x, value_type* y, value_type* left_mask, value_type* right_mask);
 void MatrixGetDiag(Matrix* matrix, value_type* diag, index_type bs);
+void MatrixSetValuesCOO(Matrix* matrix, value_type alpha, index_type n, const index_type* row, const index_type* col,
+                        const value_type* val, value_type beta);
+void MatrixSetValuesInd(Matrix* matrix, value_type alpha, index_type n, const index_type* ind, const value_type* val,
+                        value_type beta);
+void MatrixAddElemValueBatched(Matrix* matrix, index_type nshl, index_type num_batch, const index_type* batch_ptr,
+                               const index_type* ien, const value_type* val, const index_type* mask);
+/* the reference's live LHS scatter entry point (assemble.cu:253-271): one batch = one color; val holds one lda-strided
+ * block per (batch slot, a, b), `stride` values apart.  On the (u,p) MatrixFS the rows / columns 0..3 of every block go
+ * into the 4x4 block array (block mode) or through SetBlockValueToSubmatGPU into the four sub-matrices. */
 void MatrixAddElemValueBlockedBatched(Matrix* matrix, index_type nshl, index_type num_batch, const index_type* batch_ptr,
                                       const index_type* ien, index_type block_row_size, index_type block_col_size,
                                       const value_type* val, int lda, int stride, const index_type* mask);
+void MatrixAddValueBatched(Matrix* matrix, index_type batch_size, const index_type* batch_row_ind, const index_type* batch_col_ind,
+                           const value_type* A);
+void MatrixAddValueBlockedBatched(Matrix* matrix, index_type batch_size, const index_type* batch_row_ind,
+                                  const index_type* batch_col_ind, index_type block_row_size, index_type block_col_size,
+                                  const value_type* A, int lda, int stride);
+/* matrix.h:141-147 */
+MatrixCSR* MatrixCSRCreate(const CSRAttr* attr, void*);
+void MatrixCSRDestroy(Matrix* matrix);
+MatrixFS* MatrixFSCreate(index_type n_offset, const index_type* offset, void*);
+void MatrixFSDestroy(Matrix* matrix);
+/* call before MatrixSetup: keep the reference's storage (four row-expanded CSR value arrays, per-sub-matrix loops of
+ * matrix.c:449-551) instead of the 4x4 block array -- for hosts that write into MatrixCSR.val themselves */
+void MatrixFSUseReferenceLayout(Matrix* matrix, b32 on);
 /* block-mode helpers (not in the reference) */
 value_type* MatrixFSBlockValues(Matrix* matrix); /* NULL unless block mode */
 /* fills the four sub-matrices' `val` arrays (reference layout) from the block storage, allocating them on first use */
 void MatrixFSExportSubmatrices(Matrix* matrix);
 void MatrixFSImportSubmatrices(Matrix* matrix);
 /* element-partitioned runs: local nodes are numbered owned-first; rows >= n are ghost rows */
-/* y[rows row0..row1) of the (u,p) block system] = A x on those node rows only (block mode) */
-void MatrixFSMatVecRange(Matrix* m, value_type* x, value_type* y, index_type row0, index_type row1);
 void MatrixFSSetOwnedRows(Matrix* matrix, index_type n);
 /* y = A x on node rows [row0, row1) of the block-mode (u,p) system only */
 void MatrixFSMatVecRange(Matrix* matrix, value_type* x, value_type* y, index_type row0, index_type row1);
@@ -374,6 +404,9 @@ typedef struct KrylovStats {
     f64 res_hist[512]; /* |beta[k+1]| after iteration k */
     b32 converged;
     b32 fused_norm_cancelled; /* KrylovSetFusedNorm: an iteration kept < 1e-6 of w.w -- history unreliable */
+    /* running totals since the solver was created (a Newton loop makes several solves per step) */
+    index_type total_solves, total_converged;
+    int64_t total_iterations;
 } KrylovStats;
 const KrylovStats* KrylovGetStats(const Krylov* krylov);
 /* 0: GMRES tests convergence every 20 iterations like the reference (krylov.c:281-290); k>0: every k */
@@ -446,6 +479,11 @@ void DflDevicePoolStats(int64_t* reserved_bytes, int64_t* in_use_bytes);
 /* boundary group whose faces get the weak-BC terms of AssembleSystemTetFace (default 4 = the reference's hard-coded group,
  * assemble.cu:1826-1828); lists are rebuilt when the group changes */
 void DflSetWeakBCGroup(index_type group);
+/* DflSetWeakBCGroup, DflSetAssemblySchedule and the Dfl*Parameters setters below change the PROCESS DEFAULTS; every mesh
+ * copies them at Mesh3DCreate and keeps its own configuration from then on (two meshes with different schedules or face
+ * groups coexist).  The two per-mesh forms (the schedule before Mesh3DGenerateColorBatch): */
+void DflMeshSetAssemblySchedule(Mesh3D* mesh, int mode);
+void DflMeshSetWeakBCGroup(Mesh3D* mesh, index_type group);
 void DflSetQuiet(b32 quiet); /* suppress the reference's stdout chatter ("Assemble: F J", timers) */
 /* which conflict-free launches the assembly kernels execute (set BEFORE Mesh3DGenerateColorBatch):
  *   0  the reference's JPL color batches, one launch per color (reference summation order)
@@ -482,6 +520,8 @@ Array* ArrayCreateHost(index_type len);
 Array* ArrayCreateDevice(index_type len);
 void ArrayDestroy(Array* a);
 void ArrayCopy(Array* dst, const Array* src, MemCopyKind kind);
+void ArrayLoad(Array* a, H5FileInfo* h5f, const char* dataset_name);       /* Array.c:242-253; in libdedflow_h5.so */
+void ArraySave(const Array* a, H5FileInfo* h5f, const char* dataset_name); /* Array.c:255-261 */
 typedef struct ParticleContext {
     index_type num_particle;
     i32 num_pointwise_dof;
@@ -502,6 +542,9 @@ typedef struct ParticleContext {
 ParticleContext* ParticleContextCreate(index_type num_particle);
 void ParticleContextDestroy(ParticleContext* ctx);
 void ParticleContextCopy(ParticleContext* dst, const ParticleContext* src);
+/* <group_name>/{coord,vel,acc} (Particle.c:66-103); in libdedflow_h5.so */
+void ParticleContextLoad(ParticleContext* ctx, H5FileInfo* h5f, const char* group_name);
+void ParticleContextSave(const ParticleContext* ctx, H5FileInfo* h5f, const char* group_name);
 void ParticleContextUpdateHost(ParticleContext* ctx);
 void ParticleContextUpdateDevice(ParticleContext* ctx);
 void ParticleContextAdd(ParticleContext* ctx);

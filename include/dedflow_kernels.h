@@ -59,6 +59,20 @@ void dfl_dnrm2(dfl_index n, const dfl_value* x, dfl_value* d_out, dfl_value* wor
 /* x *= 1 / *d_scale  (cublasDscal with the reciprocal of a device-resident norm, krylov.c:130-131,235-237) */
 void dfl_dscal_inv_dev(dfl_index n, const dfl_value* d_scale, dfl_value* x, void* stream);
 
+/* ---- generalized-alpha state algebra of the Newton driver, one pass each (replaces the cublasDaxpy / Dcopy / Dscal /
+ *      Dnrm2 sequences of src/main.c:107-130, 242-265, 544-565; vectors are [u: Nx3 | p | phi | T]):
+ *  dfl_alpha_states  : dwgalpha = f1_0 dwgold + f1_1 dwg (p slot: dwg), wgalpha = wgold + f2_0 dwgold + f2_1 dwg (p slot: 0);
+ *                      nodep != NULL also writes the packed gather records of dfl_pack_nodes from these states and xg
+ *  dfl_alpha_predict : dwg *= fac except the p slot;   dfl_alpha_correct: wgold += c0 dwgold + c1 dwg (except p), dwgold = dwg
+ *  dfl_norms4        : d_out4[k] = ||F_u||, ||F_p||, ||F_phi||, ||F_T|| (take_sqrt = 0: sums of squares, for partitioned
+ *                      runs that all-reduce first); work >= dfl_reduce_work_size() doubles */
+void dfl_alpha_states(dfl_index N, const dfl_value* wgold, const dfl_value* dwgold, const dfl_value* dwg, dfl_value f1_0,
+                      dfl_value f1_1, dfl_value f2_0, dfl_value f2_1, const dfl_value* xg, dfl_value* wgalpha, dfl_value* dwgalpha,
+                      dfl_value* nodep, void* stream);
+void dfl_alpha_predict(dfl_index N, dfl_value fac, dfl_value* dwg, void* stream);
+void dfl_alpha_correct(dfl_index N, dfl_value c0, dfl_value c1, dfl_value* wgold, dfl_value* dwgold, const dfl_value* dwg, void* stream);
+void dfl_norms4(dfl_index N, const dfl_value* F, dfl_value* d_out4, int take_sqrt, dfl_value* work, void* stream);
+
 /* ---- fused classical Gram-Schmidt (replaces the two cublasDgemv of krylov.c:166-183
  *      and the Dnrm2 of :230).
  *   dfl_cgs_dots   : d_h[j] = Q[:,j] . w, j < ncol  (one pass over Q[:,0:ncol] and ~ncol/16 passes over w)
@@ -222,6 +236,38 @@ void SetBlockValueToSubmatGPU(dfl_value** matval, dfl_value alpha, dfl_index n_o
                               dfl_index batch_size, const dfl_index* batch_index_ptr, const dfl_index* ien, dfl_index num_row,
                               dfl_index num_col, const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val, int lda,
                               int stride, dfl_value beta, const dfl_index* mask);
+/* matrix_impl.h:29-62: the single-matrix forms of the same scatter.  (row_ptr, col_ind) is the NODAL pattern; matval is a
+ * scalar CSR array (block 1x1) or a row-expanded block_row x block_col array over it (csr_impl.cu:24-59).  The reference's
+ * kernels behind these names (matrix_impl.cu:88-208) derive (a, b) from the element id and mix two layouts -- dead code
+ * there; implemented here as their call sites describe them.  One batch must be conflict-free. */
+void MatrixCSRAddElemValueBatchedGPU(dfl_value* matval, dfl_value alpha, dfl_index batch_size, const dfl_index* batch_index_ptr,
+                                     const dfl_index* ien, dfl_index nshl, dfl_index num_row, dfl_index num_col,
+                                     const dfl_index* row_ptr, const dfl_index* col_ind, const dfl_value* val, dfl_value beta,
+                                     const dfl_index* mask);
+void MatrixCSRAddElemValueBlockedBatchedGPU(dfl_value* matval, dfl_value alpha, dfl_index batch_size, const dfl_index* batch_index_ptr,
+                                            const dfl_index* ien, dfl_index nshl, dfl_index num_row, dfl_index num_col,
+                                            const dfl_index* row_ptr, const dfl_index* col_ind, dfl_index block_row,
+                                            dfl_index block_col, const dfl_value* val, int lda, int stride, dfl_value beta,
+                                            const dfl_index* mask);
+void MatrixCSRAddElementLHSGPU(dfl_value* matval, dfl_index nshl, dfl_index bs, dfl_index num_row, const dfl_index* row_ptr,
+                               dfl_index num_col, const dfl_index* col_ind, dfl_index batch_size, const dfl_index* batch_ptr,
+                               const dfl_index* ien, const dfl_value* val, int lda);
+void MatrixCSRSetValueBatchedGPU(dfl_value* matval, dfl_value alpha, dfl_index csr_num_row, dfl_index csr_num_col,
+                                 const dfl_index* csr_row_ptr, const dfl_index* csr_col_ind, dfl_index batch_size,
+                                 const dfl_index* batch_row_ind, const dfl_index* batch_col_ind, const dfl_value* A, dfl_value beta);
+void MatrixCSRSetValueBlockedBatchedGPU(dfl_value* matval, dfl_value alpha, dfl_index csr_num_row, dfl_index csr_num_col,
+                                        const dfl_index* csr_row_ptr, const dfl_index* csr_col_ind, dfl_index batch_size,
+                                        const dfl_index* batch_row_ind, const dfl_index* batch_col_ind, dfl_index block_row,
+                                        dfl_index block_col, const dfl_value* A, dfl_value beta, int lda, int stride);
+/* the same element-block scatter straight into the 4x4 block array (block-mode MatrixFS): rows / columns 0..3 of every
+ * lda-strided (a, b) block, block = alpha * block + beta * element block */
+void dfl_bcsr_add_elem_blocked(dfl_value* block_val, dfl_value alpha, dfl_index nshl, dfl_index batch_size,
+                               const dfl_index* batch_index_ptr, const dfl_index* ien, const dfl_index* row_ptr,
+                               const dfl_index* col_ind, const dfl_value* val, int lda, int stride, dfl_value beta,
+                               const dfl_index* mask, void* stream);
+/* MatrixZeroRow on the block array: row[i] + shift = scalar row node*3 + comp of the velocity block-row; others skipped */
+void dfl_bcsr_zero_scalar_rows(dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind, dfl_value* val, dfl_index n,
+                               const dfl_index* row, dfl_index shift, dfl_value diag, void* stream);
 /* matrix_impl.h:17-26 (scalar CSR value setters; off the hot path, kept for launcher-level completeness) */
 void MatrixCSRSetValuesCOOGPU(dfl_value* matval, dfl_value alpha, dfl_index num_row, dfl_index num_col, const dfl_index* row_ptr,
                               const dfl_index* col_ind, dfl_index n, const dfl_index* row, const dfl_index* col,
@@ -322,17 +368,20 @@ void dfl_face_sum_J(dfl_index num_nz_entries, const dfl_index* fnz, const dfl_in
 /* ---- DEM contact sweep (build-defined; the reference's Particle.c holds storage only)
  *  model: monodisperse spheres, linear spring-dashpot normal contact F = (kn*overlap - gamma_n*vn) n between
  *  particles and against the six walls of the unit box; uniform cell list with cell edge >= 2R:
- *    dfl_dem_cell_index   cell_id[i] = cx + ncell*(cy + ncell*cz), order[i] = i
- *    dfl_dem_sort_by_cell stable sort of (cell_id, order) by cell; cell_start[ncell^3 + 1]; synchronises, allocates temp
+ *    dfl_dem_build_cells  counting sort of the particles by cell (4 launches, no allocation, no synchronisation):
+ *                         cell_start[ncell^3 + 1], order[P] = particle ids by (cell, id), sorted[P][6] = position and
+ *                         velocity in that order; count[ncell^3 + 1] and chunk_sum[dfl_dem_num_chunks(ncell^3)] are
+ *                         zero-initialised scratch that the call leaves zeroed again
  *    dfl_dem_forces       acc[i] = (sum_j F_ij + F_walls) / mass, neighbours from the 27 surrounding cells
  *    dfl_dem_integrate    v += dt*a ; x += dt*v */
-void dfl_dem_cell_index(dfl_index P, const dfl_value* coord, dfl_value cell, dfl_index ncell, dfl_index* cell_id,
-                        dfl_index* order, void* stream);
-void dfl_dem_sort_by_cell(dfl_index P, dfl_index* cell_id, dfl_index* order, dfl_index ncell3, dfl_index* cell_start);
+dfl_index dfl_dem_num_chunks(dfl_index ncell3);
+void dfl_dem_build_cells(dfl_index P, const dfl_value* coord, const dfl_value* vel, dfl_value cell, dfl_index ncell,
+                         dfl_index* cell_of, dfl_index* rank, dfl_index* count, dfl_index* chunk_sum, dfl_index* cell_start,
+                         dfl_index* order, dfl_value* sorted, void* stream);
 void dfl_dem_integrate(dfl_index P, dfl_value dt, dfl_value* coord, dfl_value* vel, const dfl_value* acc, void* stream);
-void dfl_dem_forces(dfl_index P, const dfl_value* coord, const dfl_value* vel, dfl_value radius, dfl_value mass, dfl_value kn,
-                    dfl_value gamma_n, dfl_value cell, dfl_index ncell, const dfl_index* order, const dfl_index* cell_start,
-                    dfl_value* acc, void* stream);
+void dfl_dem_forces(dfl_index P, const dfl_value* sorted, dfl_value radius, dfl_value mass, dfl_value kn, dfl_value gamma_n,
+                    dfl_value cell, dfl_index ncell, const dfl_index* order, const dfl_index* cell_start, dfl_value* acc,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -225,6 +225,18 @@ class System:
                _p(x), _p(b), C.c_int(maxit), C.c_double(atol), C.c_double(rtol), _p(hist), C.byref(r0))
         return x, hist[:it].copy(), float(r0.value), int(it)
 
+    def gmres_restarted(self, vals, b, restart, maxit, pc=True):
+        """GMRES(restart) as a sequence of full-GMRES cycles of the restatement above, each started from the current
+        iterate (build-defined feature: KrylovSetRestart); fixed work (atol = rtol = 0), `maxit` iterations in total."""
+        x = np.zeros(6 * self.N)
+        hist, total, r0 = [], 0, None
+        while total < maxit:
+            x, h, r, it = self.gmres(vals, b, x0=x, maxit=min(restart, maxit - total), atol=0.0, rtol=0.0, pc=pc)
+            r0 = r if r0 is None else r0
+            hist.extend(h.tolist())
+            total += it
+        return x, np.array(hist), r0, total
+
     def to_scipy(self, vals):
         """4N x 4N scipy CSR of the assembled system in the global [u|p] ordering."""
         import scipy.sparse as sp

@@ -354,7 +354,7 @@ def test_slot_owner_schedule_add_overwrite_and_bitwise_reproducible(api, oracle_
     _, vals = S.assemble_system(wg, dwg, False, True)
     L = api.lib()
     try:
-        for leaf, cap, tcap in ((16, 255, 208), (1, 40, 64), (5, 60, 40), (64, 1023, 500)):
+        for leaf, cap, tcap in ((16, 255, 208), (1, 40, 64), (5, 60, 40), (64, 1023, 500), (12, 192, 150)):
             L.DflSetSlotPatchParameters(leaf, cap, tcap)
             P = api.Problem(m, schedule=4)
             try:
@@ -411,6 +411,53 @@ def test_patch_residual_is_reproducible_and_patch_size_independent(api, oracle_l
                 P.close()
     finally:
         L.DflSetRhsPatchParameters(64, 64)
+
+
+def test_two_problems_with_different_configurations_coexist(api, oracle_lib):
+    """The assembly configuration (schedule, weak-BC face group, patch shapes) and the Newton work vectors are per mesh:
+    two problems alive in one process, assembled alternately, each match the oracle for ITS configuration."""
+    ma, mb = kuhn_cube(5, jitter=0.2), kuhn_cube(4, jitter=0.1)
+    Sa, Sb = oracle_lib.System(ma), oracle_lib.System(mb)
+    wa, dwa = synthetic_fields(ma)
+    wb, dwb = synthetic_fields(mb)
+    L = api.lib()
+    Pa = api.Problem(ma, schedule=1)                # compact colors, reference face group 4
+    L.DflSetWeakBCGroup(1)
+    Pb = api.Problem(mb, schedule=4)                # slot-owner patches, weak-BC faces on group 1
+    L.DflSetWeakBCGroup(4)
+    try:
+        da = [api.DeviceArray.from_numpy(v) for v in (wa, dwa)]
+        db = [api.DeviceArray.from_numpy(v) for v in (wb, dwb)]
+        Fa, Fb = api.DeviceArray(6 * Pa.N), api.DeviceArray(6 * Pb.N)
+        for rep in range(2):                         # alternate: a's call must not disturb b's cached schedules and vice versa
+            Pa.assemble_system(da[0], da[1], Fa, want_J=True)
+            Pb.assemble_system(db[0], db[1], Fb, want_J=True)
+        api.sync()
+        Fo, vo = Sa.assemble_system(wa, dwa, True, True)
+        ok, err = close(Fa.numpy(), Fo)
+        assert ok, err
+        for g, o in zip(Pa.export_values(), vo):
+            ok, err = close(g, o)
+            assert ok, err
+        Fo = np.zeros(6 * Sb.N)
+        vo = Sb.new_values()
+        Sb.assemble_tet(wb, dwb, Fo, vo)
+        Sb.assemble_face(wb, dwb, Fo, vo, group=1)
+        Fo[4 * Sb.N:] = 0.0
+        for group, bctype in api.REFERENCE_BCS:
+            bt, bn = np.asarray(bctype, np.int32), Sb.bnodes(group)
+            oracle_lib.lib().orc_dirichlet_vec(oracle_lib._p(Fo), C.c_int(bn.size), oracle_lib._p(bn), C.c_int(3), oracle_lib._p(bt))
+            oracle_lib.lib().orc_dirichlet_mat(C.c_int(bn.size), oracle_lib._p(bn), C.c_int(3), oracle_lib._p(bt), C.c_int(Sb.N),
+                                               oracle_lib._p(Sb.rp33), oracle_lib._p(Sb.ci33), oracle_lib._p(vo[0]),
+                                               oracle_lib._p(Sb.rp31), oracle_lib._p(Sb.ci31), oracle_lib._p(vo[1]))
+        ok, err = close(Fb.numpy(), Fo)
+        assert ok, err
+        for g, o in zip(Pb.export_values(), vo):
+            ok, err = close(g, o)
+            assert ok, err
+    finally:
+        Pa.close()
+        Pb.close()
 
 
 def test_wave_residual_is_reproducible_and_shape_independent(api, oracle_lib):
@@ -470,6 +517,46 @@ def test_geometry_cache_follows_moved_nodes(api, oracle_lib):
         for g, o in zip(P.export_values(), vals2):
             ok, err = close(g, o)
             assert ok, err
+    finally:
+        P.close()
+
+
+def test_restarted_gmres_matches_the_oracle_cycles(api, oracle_lib):
+    """KrylovSetRestart(m): GMRES(m) = full-GMRES cycles of the restatement of krylov.c:56-334, each from the current
+    iterate (fixed work: atol = rtol = 0).  m >= max_iter is the reference's full GMRES: bitwise the same history as the
+    default path."""
+    m = kuhn_cube(6, jitter=0.2)
+    wg, dwg = synthetic_fields(m)
+    S = oracle_lib.System(m)
+    F, vals = S.assemble_system(wg, dwg, True, True)
+    L = api.lib()
+    P = api.Problem(m, maxit=45, atol=0.0, rtol=0.0)
+    try:
+        wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+        F_d, x_d = api.DeviceArray(6 * P.N), api.DeviceArray(6 * P.N)
+        P.assemble_system(wg_d, dwg_d, F_d, want_J=False)
+        P.assemble_system(wg_d, dwg_d, None, want_J=True)
+        it0, r00, h0, _ = P.solve(x_d, F_d)
+        x0 = x_d.numpy().copy()
+        L.KrylovSetRestart(P.ksp, 200)      # >= max_iter: same code path, same bits
+        x_d.zero()
+        it1, r01, h1, _ = P.solve(x_d, F_d)
+        assert it1 == it0 == 45 and r01 == r00 and np.array_equal(h1, h0) and np.array_equal(x_d.numpy(), x0)
+        L.KrylovSetRestart(P.ksp, 15)
+        x_d.zero()
+        it2, r02, h2, _ = P.solve(x_d, F_d)
+        xo, ho, r0o, ito = S.gmres_restarted(vals, F, 15, 45)
+        assert it2 == ito == 45 and abs(r02 - r0o) <= 1e-12 * r0o
+        k = np.arange(1, 46)
+        assert np.all(np.abs(h2 - ho) <= 1e-10 * r0o * np.maximum(1.0, k / 10.0))
+        assert np.array_equal(h2[:15], h0[:15])            # the first cycle IS the full-GMRES start
+        ok, err = close(x_d.numpy(), xo, 1e-8)
+        assert ok, err
+        # the restarted recurrence restarts from the TRUE residual: ||b - A x|| after the solve equals the last entry
+        y_d = api.DeviceArray(6 * P.N)
+        P.matvec(x_d, y_d)
+        true = np.linalg.norm(F[:4 * P.N] - y_d.numpy()[:4 * P.N])
+        assert abs(true - h2[-1]) <= 1e-9 * r0o
     finally:
         P.close()
 

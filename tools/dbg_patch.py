@@ -20,7 +20,7 @@ L.MatrixZero(P.J)
 P.assemble_tet(wg_d, dwg_d, None, want_J=True)
 api.sync()
 REPS = int(os.environ.get('DFL_DBG_REPS', 20))
-seq = (0,) if len(sys.argv) > 3 else ((0, 1, 2, 4, 6, 8, 0) if mode == 4 else (0, 8, 2, 10, 1, 3, 0))
+seq = (0,) if len(sys.argv) > 3 else ((0, 16, 1, 2, 4, 6, 8, 24, 0) if mode == 4 else (0, 8, 2, 10, 1, 3, 0))
 for dbg in seq:
     L.dfl_tune_asm(dbg)
     for rep in range(3):

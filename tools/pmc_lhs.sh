@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "lhs" not in k: continue
+        if "lhs" not in k or "pack" in k: continue
         acc[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)

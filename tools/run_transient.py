@@ -1,6 +1,6 @@
 """Transient loop in the shape of BASELINE config 5 on ONE GPU: M-cube mesh, PC_ILU0 (multicolor block-DILU) or the Jacobi tree,
 `steps` generalized-alpha time steps through DflTimeStep; prints per-step time, Newton/GMRES work and the device-memory footprint.
-  python tools/run_transient.py [M=203] [steps=5] [pc=dilu|jacobi] [newton=2] [gmres_maxit=120]"""
+  python tools/run_transient.py [M=203] [steps=5] [pc=dilu|jacobi] [newton=2] [gmres_maxit=120] [restart=0]"""
 import sys, os, time, json, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 pc = sys.argv[3] if len(sys.argv) > 3 else "dilu"
 newton = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 maxit = int(sys.argv[5]) if len(sys.argv) > 5 else 120
+restart = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 t0 = time.perf_counter()
 mesh = kuhn_cube(M, jitter=0.2)
 wg, dwg = synthetic_fields(mesh)
@@ -20,6 +21,7 @@ wg[3 * N:4 * N] = 0.0
 L = api.lib()
 P = api.Problem(mesh, maxit=maxit, atol=1e-12, rtol=1e-4, quiet=True)
 L.KrylovSetPCType(P.ksp, api.PC_ILU0 if pc == "dilu" else api.PC_DECOMPOSITION)
+L.KrylovSetRestart(P.ksp, restart)
 st = [api.DeviceArray.from_numpy(a) for a in (wg, 0.1 * dwg, 0.1 * dwg)]
 F, dx = api.DeviceArray(6 * N), api.DeviceArray(6 * N)
 api.sync()
@@ -31,8 +33,8 @@ for s in range(steps):
     it, rn, r0 = P.time_step(st[0], st[1], st[2], F, dx, newton_maxit=newton)
     api.sync(); times.append(time.perf_counter() - t)
     stt = L.KrylovGetStats(P.ksp).contents
-    print("step %d: %.1f ms, %d Newton iterations, last GMRES %d its (converged=%d), |R_u| %.3e -> %.3e" %
-          (s + 1, 1e3 * times[-1], it, stt.iterations, stt.converged, r0[0], rn[0]), flush=True)
+    print("step %d: %.1f ms, %d Newton iterations, last GMRES %d its (converged=%d), solves so far %d (converged %d, %d iterations), |R_u| %.3e -> %.3e" %
+          (s + 1, 1e3 * times[-1], it, stt.iterations, stt.converged, stt.total_solves, stt.total_converged, stt.total_iterations, r0[0], rn[0]), flush=True)
 r, u = C.c_int64(0), C.c_int64(0)
 L.DflDevicePoolStats(C.byref(r), C.byref(u))
 free_b, tot_b = C.c_size_t(0), C.c_size_t(0)
