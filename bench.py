@@ -15,7 +15,8 @@ bytes of SURVEY.md 8(d) / BASELINE.md 3.
 
 N=1 workload: the 10M-tet cube (M=119) BASELINE.json's metric is quoted on.
 N>1: the same mesh, element-partitioned over N ranks (strong scaling), halo exchange +
-all-reduce through torch.distributed (backend nccl = RCCL).
+all-reduce on RCCL (bootstrap through torch.distributed, backend nccl).  `python bench.py --gpus N`
+starts the N ranks itself (torch.distributed.run, 127.0.0.1) when it was not launched by it.
 """
 import argparse
 import ctypes as C
@@ -39,10 +40,11 @@ def algorithmic_bytes(N, T, nnz1, its):
     n4 = 4 * N
     return {
         "spmv": 132.0 * nnz1 + 4.0 * (N + 1) + 64.0 * N,                      # per matvec
-        # per J assembly, row-owner schedule: every block line written once + slot map, per tet
-        # connectivity + geometry record + 4 items x 12 B, one packed record per node.  (The reference's
-        # colored scatter, SURVEY 8(d), is 4116*T + 120*N: every block line read+written once per tet.)
-        "asm_lhs": 132.0 * nnz1 + T * (16.0 + 128.0 + 48.0) + 128.0 * N,
+        # per J assembly: SURVEY 8(d)'s COMPULSORY FLOOR (every block line written once, connectivity once, node fields
+        # once) -- the slot-owner kernel moves more than this (slot map, contribution descriptors, per-patch connectivity;
+        # DESIGN.md section 3), so the fraction is conservative.  The reference-shaped colored scatter (4116*T + 120*N:
+        # every block line read+written once per tet) is reported next to it.
+        "asm_lhs": 128.0 * nnz1 + 16.0 * T + 120.0 * N,
         "asm_lhs_colored": T * (16.0 + 4.0 + 4096.0) + 120.0 * N,
         "asm_rhs": T * (20.0 + 384.0) + 120.0 * N,                           # per F assembly
         "pc_apply": (9 + 1) * 8.0 * N + 2 * 8.0 * n4,                        # per apply
@@ -90,8 +92,9 @@ def cpu_baseline(M_sample, its):
     out = dict(multi)
     out.update({
         "unit": "DOF/s", "kind": "port",
-        "sample": f"Kuhn cube M={M_sample} ({S.T} tets, {S.N} nodes), same step (F + J assembly, {its} GMRES its), "
-                  f"oracle/liboracle.so with OpenMP on {ncores} host threads",
+        "sample": f"SMALLER mesh than the GPU line: Kuhn cube M={M_sample} ({S.T} tets, {S.N} nodes), same step (F + J "
+                  f"assembly, {its} GMRES its), oracle/liboracle.so with OpenMP on {ncores} host threads; `value` is DOF/s "
+                  f"of that sample, i.e. a per-DOF rate to be read against the 10M-tet GPU line as an extrapolation",
         "single_thread": single,
     })
     return out
@@ -106,6 +109,7 @@ def main():
     ap.add_argument("--gmres-its", type=int, default=40)
     ap.add_argument("--cpu-M", type=int, default=64, help="cube size of the CPU-baseline sample (0 = skip); 64 = 1.57M tets, ~10-15 s of CPU work")
     ap.add_argument("--jitter", type=float, default=0.2)
+    ap.add_argument("--solve-to-rtol", type=int, default=1, help="also time one PC_ILU0 solve to rtol 1e-4 after the timed steps (0 = skip)")
     ap.add_argument("--coupled-M", type=int, default=55, help="fluid mesh of the coupled fluid + DEM step leg (0 = skip)")
     ap.add_argument("--dem-particles", type=int, default=100000, help="DEM contact sweep leg after the timed step (0 = skip)")
     args = ap.parse_args()
@@ -113,7 +117,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1 or os.environ.get("DFL_FORCE_DIST") == "1":  # DFL_FORCE_DIST: rehearse the N>1 leg on one rank
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torch.distributed.run with the
+        # loopback rendezvous) as a CHILD process -- nothing in this process has touched the GPU yet -- and relay its output
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if world > 1 and args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    if world > 1 or os.environ.get("DFL_FORCE_DIST") == "1":  # DFL_FORCE_DIST: rehearse the N>1 leg on one rank
         from dedflow_amd import dist_bench
         return dist_bench.run(args, rank, world, local_rank)
 
@@ -196,13 +214,14 @@ def main():
                          "frac_of_8TBps": gbps / HBM_PEAK_GBS, "bytes": unit_desc}
 
     c, t, _ = prof["spmv"]; entry("spmv", ab["spmv"] * c, c, t, "132*nnz1+4(N+1)+64N per launch")
-    c, t, _ = prof["asm_lhs"]; entry("asm_lhs", ab["asm_lhs"] * K, c, t, "132*nnz1+192*T+128N per J assembly (row-owner patches, one launch; "
-                                                                      "the colored scatter of SURVEY 8(d) would move 4116*T+120N)")
+    c, t, _ = prof["asm_lhs"]; entry("asm_lhs", ab["asm_lhs"] * K, c, t, "128*nnz1+16*T+120N per J assembly = SURVEY 8(d) compulsory floor "
+                                                                      "(slot-owner node patches, ONE launch, no atomics; the "
+                                                                      "colored scatter of SURVEY 8(d) would move 4116*T+120N)")
     if "asm_lhs" in kernels:  # the same time against the bytes the reference-shaped colored scatter would move
         eq = ab["asm_lhs_colored"] * K / (prof["asm_lhs"][1] * 1e-3) / 1e9
         kernels["asm_lhs"].update({"colored_scatter_bytes_per_assembly": ab["asm_lhs_colored"],
                                    "GBps_equivalent_colored_scatter": eq, "frac_of_8TBps_equivalent_colored_scatter": eq / HBM_PEAK_GBS})
-    c, t, _ = prof["asm_rhs"]; entry("asm_rhs", ab["asm_rhs"] * K, c, t, "404*T+120N per F assembly (one launch per color)")
+    c, t, _ = prof["asm_rhs"]; entry("asm_rhs", ab["asm_rhs"] * K, c, t, "404*T+120N per F assembly (wave-per-patch kernel + ordered node sum: 2 launches)")
     c, t, _ = prof["pc_apply"]; entry("pc_apply", ab["pc_apply"] * c, c, t, "80N+64N per apply")
     cd, td, _ = prof["cgs_dots"]; cu, tu, _ = prof["cgs_update"]
     entry("cgs", sum(ab["cgs"]) * K, cd + cu, td + tu, "2*8*4N*(k+1)+24*4N per Arnoldi step k")
@@ -225,6 +244,37 @@ def main():
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": kd["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kd["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": kd["avg_ms"]}
+
+    # ---- AssembleSystem end to end (pack, element kernels, weak-BC faces, Dirichlet rows / entries), one event pair per call
+    asm_t = api.Timer()
+    asm_ms = {"F": [], "J": []}
+    for _ in range(5):
+        asm_t.start(); P.assemble_system(wg_d, dwg_d, F_d, want_J=False); asm_t.stop(); asm_ms["F"].append(asm_t.ms())
+        asm_t.start(); P.assemble_system(wg_d, dwg_d, None, want_J=True); asm_t.stop(); asm_ms["J"].append(asm_t.ms())
+    asm_F_ms, asm_J_ms = float(np.median(asm_ms["F"])), float(np.median(asm_ms["J"]))
+
+    # ---- time to the reference's tolerance (rtol 1e-4, main.c:406) on the same system: full GMRES, PC_ILU0 (multicolor
+    # block-DILU; the Jacobi tree does not reach 1e-4 within 300 iterations at this size) -- outside the timed steps
+    to_rtol = None
+    if args.solve_to_rtol:
+        L.KrylovSetPCType.argtypes = [C.c_void_p, C.c_int]
+        ksp_i = C.cast(P.ksp, C.POINTER(C.c_int32))
+        ksp_f = C.cast(P.ksp, C.POINTER(C.c_double))
+        ksp_i[0] = 300                    # Krylov.max_iter
+        ksp_f[1], ksp_f[2] = 1e-12, 1e-4  # Krylov.atol, rtol
+        L.KrylovSetPCType(P.ksp, api.PC_ILU0)
+        res = []
+        for rep in range(2):              # the first solve builds the DILU coloring and grows the basis
+            x_d.zero()
+            api.sync(); tw = time.perf_counter()
+            it2, r02, hist2, conv2 = P.solve(x_d, F_d)
+            api.sync(); res.append(time.perf_counter() - tw)
+        to_rtol = {"pc": "PC_ILU0 (multicolor block-DILU)", "rtol": 1e-4, "iterations": it2, "converged": bool(conv2),
+                   "ms": 1e3 * res[-1], "relative_residual": float(hist2[-1] / r02) if len(hist2) else None,
+                   "dofs_per_s": 4.0 * N / res[-1]}
+        L.KrylovSetPCType(P.ksp, api.PC_DECOMPOSITION)
+        ksp_i[0] = its
+        ksp_f[1], ksp_f[2] = 0.0, 0.0
 
     cpu = cpu_baseline(args.cpu_M, its) if args.cpu_M > 0 else None
 
@@ -301,8 +351,13 @@ def main():
                                f"AssembleSystem(J) + Jacobi-PC GMRES x{its} iterations",
                    "colors": P.num_color, "gmres_its": its, "parallelism": "1 GPU"},
         "spmv_GBps": kernels.get("spmv", {}).get("GBps"), "spmv_frac_of_hbm_peak": kernels.get("spmv", {}).get("frac_of_8TBps"),
-        "assemble_J_dofs_per_s": (4.0 * N / (tJ * 1e-3)) if tJ else None,
-        "assemble_F_dofs_per_s": (6.0 * N / (tF * 1e-3)) if tF else None,
+        # whole AssembleSystem calls (pack + element kernels + faces + Dirichlet), event-timed; the element kernels alone
+        # are in `kernels` (asm_lhs / asm_rhs)
+        "assemble_J_dofs_per_s": 4.0 * N / (asm_J_ms * 1e-3), "assemble_F_dofs_per_s": 6.0 * N / (asm_F_ms * 1e-3),
+        "assemble_J_ms": asm_J_ms, "assemble_F_ms": asm_F_ms,
+        "assemble_J_kernel_dofs_per_s": (4.0 * N / (tJ * 1e-3)) if tJ else None,
+        "assemble_F_kernel_dofs_per_s": (6.0 * N / (tF * 1e-3)) if tF else None,
+        "solve_to_rtol": to_rtol,
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "dem_sweep": dem,
         "spmv_back_to_back_ms": spmv_grouped_ms, "coupled_step": coupled,
         # the whole Krylov solve against the HBM roofline: algorithmic bytes of its `its` matvecs (x0 = 0: r0 = b needs none),

@@ -191,16 +191,14 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, 
                     const d2a* r2 = reinterpret_cast<const d2a*>(rec);
                     const d2a ca01 = r2[6 + aa * 2], ca23 = r2[7 + aa * 2], cb01 = r2[6 + bb * 2], cb23 = r2[7 + bb * 2];
                     const d2a ta01 = r2[14], ta23 = r2[15], sc = r2[16];
+                    const double cb_a = rec[12 + bb * 4 + aa], ca_b = rec[12 + aa * 4 + bb], t0_b = rec[28 + bb];
                     ca[0] = ca01.x; ca[1] = ca01.y; ca[2] = ca23.x; ca[3] = ca23.y;
                     cb[0] = cb01.x; cb[1] = cb01.y; cb[2] = cb23.x; cb[3] = cb23.y;
                     t0q[0] = ta01.x; t0q[1] = ta01.y; t0q[2] = ta23.x; t0q[3] = ta23.y;
                     if (PROBE && (dbg & 4)) {
-                        acc[0] += ga[0] + gb[1] + ca[2] + cb[3] + t0q[0] + sc.x + sc.y;
+                        acc[0] += ga[0] + gb[1] + ca[2] + cb[3] + t0q[0] + sc.x + sc.y + cb_a + ca_b + t0_b;
                     } else {
-                        double Bk[16];
-                        lhs_block_eval_s(aa, bb, ga, gb, sc.y, t0q, sc.x, ca, cb, Bk);
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[i] += Bk[i];
+                        lhs_block_accumulate(aa == bb, ga, gb, sc.y, t0q, sc.x, ca, cb, cb_a, ca_b, t0_b, acc);
                     }
                     d = dn;
                     c += 4;

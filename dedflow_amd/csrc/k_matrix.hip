@@ -30,14 +30,20 @@ __device__ __forceinline__ d2v ld_val(const d2v* p) {
 //            instruction), 1 = developer probe without the store, 2 = as 0 with nontemporal stores,
 //        3 = the 32 rows of a workgroup are staged in LDS and written by ONE wave instruction as whole lines
 //            (48 lanes x 16 B of the velocity part + 16 lanes x 16 B of the pressure part)
-template <bool BETA0, bool NT, int U, bool XCD = false, int STORE = 0>
+// CHUNK > 0 (with XCD): instead of ONE slab per XCD, the XCDs take chunks of CHUNK consecutive workgroups round-robin:
+//        the eight row ranges being read and written at any moment are neighbours (one moving window over val / y)
+//        rather than eight streams a fixed 1/8 of the arrays apart
+template <bool BETA0, bool NT, int U, bool XCD = false, int STORE = 0, int CHUNK = 0>
 __global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I row0, I nrows, I N, const I* __restrict__ rp, const I* __restrict__ ci,
                                                        const T* __restrict__ val, T alpha, const T* __restrict__ x, T beta,
                                                        T* __restrict__ y) {
     // XCD: workgroup b runs on XCD b % 8 (one L2 each); hand every XCD one contiguous slab of rows so that the x
     // entries shared by neighbouring rows are fetched into ONE L2 instead of up to eight
     long long blk = blockIdx.x;
-    if (XCD) {
+    if (XCD && CHUNK > 0) {
+        const long long i = blk >> 3, xcd = blk & 7;
+        blk = ((i / CHUNK) * 8 + xcd) * CHUNK + (i % CHUNK);  // grid is a multiple of 8 * CHUNK
+    } else if (XCD) {
         const long long per = gridDim.x >> 3;  // grid is a multiple of 8
         blk = (blk & 7) * per + (blk >> 3);
     }
@@ -119,6 +125,7 @@ __global__ __launch_bounds__(BLK) void bcsr_spmv_kernel(I row0, I nrows, I N, co
 }
 
 int g_spmv_variant = 4;
+int g_pc_apply_mode = 0;
 
 // scalar CSR, 8 lanes per row (reference-layout sub-matrices)
 __global__ __launch_bounds__(BLK) void csr_spmv_kernel(I nrow, const I* __restrict__ rp, const I* __restrict__ ci,
@@ -183,23 +190,39 @@ __global__ __launch_bounds__(BLK) void pc_setup_kernel(I nrows, const I* rp, con
 }
 
 // PCDecompositionApply (pc.c:136-147): z_u = inv(D)^T r_u (Q7), z_p = r_p * dinv1, tail copied.
-template <bool SCALED>
+// MODE (developer A/B, dfl_tune(1, mode)): bit 0 = XCD-aware node ranges (workgroup b writes the rows that XCD b % 8 reads in
+// the SpMV that follows), bit 1 = nontemporal store of the normalised column q, bit 2 = nontemporal store of y
+template <bool SCALED, int MODE = 0>
 __global__ __launch_bounds__(BLK) void pc_apply_kernel(I nrows, I N, const T* __restrict__ dinv33, const T* __restrict__ dinv1,
                                                       const T* __restrict__ x, const T* __restrict__ d_nrm, T* __restrict__ q,
                                                       T* __restrict__ y) {
-    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    long long blk = blockIdx.x;
+    if (MODE & 1) {
+        const long long per = gridDim.x >> 3;  // grid is a multiple of 8
+        blk = (blk & 7) * per + (blk >> 3);
+    }
+    const long long i = blk * BLK + threadIdx.x;
     const double s = SCALED ? 1.0 / d_nrm[0] : 1.0;
     if (i < nrows) {
         const T* A = dinv33 + i * 9;  // column-major image: A(r,c) = A[r + 3c]
         double x0 = x[3 * i], x1 = x[3 * i + 1], x2 = x[3 * i + 2], xp = x[3LL * N + i];
         if (SCALED) {
             x0 *= s; x1 *= s; x2 *= s; xp *= s;
-            q[3 * i] = x0; q[3 * i + 1] = x1; q[3 * i + 2] = x2; q[3LL * N + i] = xp;
+            if (MODE & 2) {
+                __builtin_nontemporal_store(x0, q + 3 * i); __builtin_nontemporal_store(x1, q + 3 * i + 1);
+                __builtin_nontemporal_store(x2, q + 3 * i + 2); __builtin_nontemporal_store(xp, q + 3LL * N + i);
+            } else {
+                q[3 * i] = x0; q[3 * i + 1] = x1; q[3 * i + 2] = x2; q[3LL * N + i] = xp;
+            }
         }
-        y[3 * i + 0] = A[0] * x0 + A[3] * x1 + A[6] * x2;
-        y[3 * i + 1] = A[1] * x0 + A[4] * x1 + A[7] * x2;
-        y[3 * i + 2] = A[2] * x0 + A[5] * x1 + A[8] * x2;
-        y[3LL * N + i] = xp * dinv1[i];
+        const double y0 = A[0] * x0 + A[3] * x1 + A[6] * x2, y1 = A[1] * x0 + A[4] * x1 + A[7] * x2;
+        const double y2 = A[2] * x0 + A[5] * x1 + A[8] * x2, yp = xp * dinv1[i];
+        if (MODE & 4) {
+            __builtin_nontemporal_store(y0, y + 3 * i); __builtin_nontemporal_store(y1, y + 3 * i + 1);
+            __builtin_nontemporal_store(y2, y + 3 * i + 2); __builtin_nontemporal_store(yp, y + 3LL * N + i);
+        } else {
+            y[3 * i + 0] = y0; y[3 * i + 1] = y1; y[3 * i + 2] = y2; y[3LL * N + i] = yp;
+        }
     }
 }
 
@@ -531,6 +554,10 @@ void dfl_bcsr_spmv_range(I row0, I row1, I N, const I* rp, const I* ci, const T*
             case 5: bcsr_spmv_kernel<true, true, 4, true, 1><<<grid8, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
             case 6: bcsr_spmv_kernel<true, true, 4, true, 2><<<grid8, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
             case 7: bcsr_spmv_kernel<true, true, 4, true, 3><<<grid8, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
+            case 8: bcsr_spmv_kernel<true, true, 4, true, 0, 64><<<(grid + 511) / 512 * 512, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
+            case 9: bcsr_spmv_kernel<true, true, 4, true, 0, 512><<<(grid + 4095) / 4096 * 4096, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
+            case 10: bcsr_spmv_kernel<true, true, 4, true, 3, 64><<<(grid + 511) / 512 * 512, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
+            case 11: bcsr_spmv_kernel<true, true, 4, true, 0, 8><<<(grid + 63) / 64 * 64, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
             default: bcsr_spmv_kernel<true, true, 4, true><<<grid8, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
         }
     } else {
@@ -612,6 +639,7 @@ void dfl_bcsr_zero_scalar_rows(I N, const I* rp, const I* ci, T* val, I n, const
 /* kernel-variant selection for A/B measurements (key 0: block-CSR SpMV variant 0..4; 4 = default, XCD-aware row slabs) */
 void dfl_tune(int key, int value) {
     if (key == 0) g_spmv_variant = value;
+    if (key == 1) g_pc_apply_mode = value;
 }
 void dfl_bcsr_spmv(I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
     dfl_bcsr_spmv_rows(N, N, rp, ci, val, alpha, x, beta, y, stream);
@@ -644,7 +672,17 @@ void dfl_pc_jacobi_apply(I N, I n, const T* dinv33, const T* dinv1, const T* x, 
 
 void dfl_pc_jacobi_apply_scaled_rows(I nrows, I N, I n, const T* dinv33, const T* dinv1, const T* w, const T* d_nrm, T* q_out,
                                      T* y, void* stream) {
-    if (nrows > 0) pc_apply_kernel<true><<<ceil_div(nrows, BLK), BLK, 0, S(stream)>>>(nrows, N, dinv33, dinv1, w, d_nrm, q_out, y);
+    if (nrows > 0) {
+        const int g = ceil_div(nrows, BLK), g8 = (g + 7) & ~7;
+        switch (g_pc_apply_mode) {
+            case 1: pc_apply_kernel<true, 1><<<g8, BLK, 0, S(stream)>>>(nrows, N, dinv33, dinv1, w, d_nrm, q_out, y); break;
+            case 2: pc_apply_kernel<true, 2><<<g, BLK, 0, S(stream)>>>(nrows, N, dinv33, dinv1, w, d_nrm, q_out, y); break;
+            case 3: pc_apply_kernel<true, 3><<<g8, BLK, 0, S(stream)>>>(nrows, N, dinv33, dinv1, w, d_nrm, q_out, y); break;
+            case 4: pc_apply_kernel<true, 4><<<g, BLK, 0, S(stream)>>>(nrows, N, dinv33, dinv1, w, d_nrm, q_out, y); break;
+            case 6: pc_apply_kernel<true, 6><<<g, BLK, 0, S(stream)>>>(nrows, N, dinv33, dinv1, w, d_nrm, q_out, y); break;
+            default: pc_apply_kernel<true><<<g, BLK, 0, S(stream)>>>(nrows, N, dinv33, dinv1, w, d_nrm, q_out, y); break;
+        }
+    }
     if (n > 4 * N)
         tail_copy_kernel<<<ceil_div((long long)n - 4LL * N, BLK), BLK, 0, S(stream)>>>(4LL * N, n, w, d_nrm, q_out, y);
     DFL_LAUNCH_CHECK();

@@ -123,6 +123,7 @@ void DflProfileEnable(int on);
 int DflProfileBegin(int tag);
 void DflProfileEnd(int slot);
 int DflProfileCollect(int tag, double* total_ms, double* min_ms);
+int DflProfileDurations(int tag, double* out_ms, int max_out);
 #define DFL_TIMED(tag, call) do { int _s = DflProfileBegin(tag); call; DflProfileEnd(_s); } while (0)
 
 /* AssembleSystem for the Newton driver: `prepacked` = the packed node records were just written from these very states
@@ -130,6 +131,9 @@ int DflProfileCollect(int tag, double* total_ms, double* min_ms);
 void DflAssembleSystemPrepacked(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, Dirichlet** bcs, index_type nbc,
                                 b32 prepacked);
 f64* DflMeshNodeRecords(Mesh3D* mesh); /* [N][16] packed gather records, allocated on first use */
+void DflKrylovWorkspaceInPool(int on);
+void* DflVectorArenaAlloc(size_t bytes);
+int DflVectorArenaFree(void* p);
 /* driver.c */
 index_type SolveFlowSystem(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* J, f64* F, f64* dx, Krylov* ksp,
                            Dirichlet** bcs, index_type nbc, index_type maxit, f64* rnorm_out, f64* rnorm_init_out);

@@ -13,6 +13,9 @@ static void pool_release_all(void);
 struct PoolChunk;
 static struct PoolChunk* pool_new_chunk(size_t bytes);
 static int g_pool_state;
+static char* g_varena = NULL;
+static size_t g_varena_size = 0, g_varena_off = 0;
+static int g_varena_live = 0;
 static int g_nchunk;
 static size_t g_chunk_bytes;
 
@@ -39,6 +42,31 @@ void Init(int argc, char** argv) {
     /* reserve the first pool chunk while VRAM is pristine (see "device memory pool" below) */
     pool_configure();
     if (g_pool_state == 1 && g_nchunk == 0) (void)pool_new_chunk(g_chunk_bytes);
+    /* optional second early reservation for solver vectors (DFL_VECTOR_ARENA_GB, developer A/B; see host/solver.c) */
+    {
+        const char* e = getenv("DFL_VECTOR_ARENA_GB");
+        double gb = e ? atof(e) : 0.0;
+        if (gb > 0.0 && !g_varena) {
+            g_varena_size = (size_t)(gb * 1073741824.0);
+            if (hipMalloc((void**)&g_varena, g_varena_size) != hipSuccess) { (void)hipGetLastError(); g_varena = NULL; g_varena_size = 0; }
+        }
+    }
+}
+
+/* bump allocator over the vector arena: returns NULL when the arena is absent or full; the arena is reused from the start
+ * once everything taken from it has been returned */
+void* DflVectorArenaAlloc(size_t bytes) {
+    bytes = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    if (!g_varena || g_varena_off + bytes > g_varena_size) return NULL;
+    void* p = g_varena + g_varena_off;
+    g_varena_off += bytes;
+    g_varena_live++;
+    return p;
+}
+int DflVectorArenaFree(void* p) {
+    if (!g_varena || (char*)p < g_varena || (char*)p >= g_varena + g_varena_size) return 0;
+    if (--g_varena_live == 0) g_varena_off = 0;
+    return 1;
 }
 
 void Finalize(void) {
@@ -285,6 +313,18 @@ int DflProfileBegin(int tag) {
 }
 void DflProfileEnd(int slot) {
     if (slot >= 0) HIPGUARD(hipEventRecord(g_ev[slot].b, g_stream));
+}
+/* the individual durations (ms) of the recorded intervals with this tag, in launch order; returns how many were written */
+int DflProfileDurations(int tag, double* out_ms, int max_out) {
+    int count = 0;
+    HIPGUARD(hipStreamSynchronize(g_stream));
+    for (int i = 0; i < g_ev_n && count < max_out; ++i) {
+        if (g_ev[i].tag != tag) continue;
+        float ms = 0.f;
+        HIPGUARD(hipEventElapsedTime(&ms, g_ev[i].a, g_ev[i].b));
+        out_ms[count++] = ms;
+    }
+    return count;
 }
 /* sums the elapsed time of every recorded interval with this tag; synchronises */
 int DflProfileCollect(int tag, double* total_ms, double* min_ms) {

@@ -217,6 +217,8 @@ typedef struct KrylovExt {
     int* d_flag;    /* device int raised by the fused-norm kernel on heavy cancellation */
     /* cached GMRES work space */
     index_type ws_n, ws_maxit, ws_hist;
+    int ws_pooled; /* where Q and tmp of the cached work space came from */
+    b32 ws_fresh;  /* the basis was (re)allocated and its placement has not been calibrated yet */
     f64 *Q, *H, *tmp, *gv, *beta, *res_hist, *nrm, *work;
     int64_t work_len;
 } KrylovExt;
@@ -258,8 +260,32 @@ void KrylovSetComm(Krylov* k, const DflComm* comm) {
     if (comm) x->comm = *comm;
 }
 
+/* The Krylov basis and the preconditioned vector live OUTSIDE the device pool, in allocations of their own.  Measured on
+ * MI355X (tools/probe_spmv_r2c.py, profiles/r02_spmv_placement.txt): the block-CSR SpMV takes 0.673 ms when its output
+ * vector lies in the same 32 GiB pool chunk as the 3.3 GB value array it streams, and 0.570 ms when the output lies in any
+ * other allocation (0.554 ms with the store compiled out) -- reads of the value array and writes of y compete when both
+ * come from one physical neighbourhood.  DFL_KRYLOV_POOL=1 puts them back into the pool (A/B). */
+static int g_ws_pool = -1; /* process default; DflKrylovWorkspaceInPool switches it (developer A/B) */
+static int ws_in_pool(void) {
+    if (g_ws_pool < 0) { const char* e = getenv("DFL_KRYLOV_POOL"); g_ws_pool = (e && atoi(e) == 1) ? 1 : 0; }
+    return g_ws_pool;
+}
+static f64* ws_vec_malloc(ptrdiff_t count) {
+    if (ws_in_pool()) return (f64*)CdamMallocDevice(count * SIZE_OF(f64));
+    void* p = DflVectorArenaAlloc((size_t)count * sizeof(f64));
+    if (!p) HIPGUARD(hipMalloc(&p, (size_t)count * sizeof(f64)));
+    HIPGUARD(hipMemsetAsync(p, 0, (size_t)count * sizeof(f64), DflStream()));
+    return (f64*)p;
+}
+void DflKrylovWorkspaceInPool(int on) { g_ws_pool = on ? 1 : 0; } /* takes effect at the next solve of every solver */
+static void ws_vec_free_as(f64* p, int pooled) {
+    if (!p) return;
+    if (pooled) CdamFreeDevice(p, 0);
+    else if (!DflVectorArenaFree(p)) HIPGUARD(hipFree(p));
+}
+
 static void ws_free(KrylovExt* x) {
-    CdamFreeDevice(x->Q, 0); CdamFreeDevice(x->H, 0); CdamFreeDevice(x->tmp, 0); CdamFreeDevice(x->gv, 0);
+    ws_vec_free_as(x->Q, x->ws_pooled); CdamFreeDevice(x->H, 0); ws_vec_free_as(x->tmp, x->ws_pooled); CdamFreeDevice(x->gv, 0);
     CdamFreeDevice(x->beta, 0); CdamFreeDevice(x->res_hist, 0); CdamFreeDevice(x->nrm, 0); CdamFreeDevice(x->work, 0);
     CdamFreeDevice(x->d_flag, 0);
     x->d_flag = NULL;
@@ -269,11 +295,12 @@ static void ws_free(KrylovExt* x) {
 
 /* maxit = basis columns per cycle (the restart length, or max_iter for full GMRES); hist = entries of the residual history */
 static void ws_ensure(KrylovExt* x, index_type n, index_type maxit, index_type ldh, index_type hist) {
-    if (x->ws_n == n && x->ws_maxit == maxit && x->ws_hist >= hist) return;
+    if (x->ws_n == n && x->ws_maxit == maxit && x->ws_hist >= hist && x->ws_pooled == ws_in_pool()) return;
     ws_free(x);
-    x->Q = (f64*)CdamMallocDevice((ptrdiff_t)n * SIZE_OF(f64) * (maxit + 1));
+    x->ws_pooled = ws_in_pool();
+    x->Q = ws_vec_malloc((ptrdiff_t)n * (maxit + 1));
     x->H = (f64*)CdamMallocDevice((ptrdiff_t)ldh * maxit * SIZE_OF(f64));
-    x->tmp = (f64*)CdamMallocDevice((ptrdiff_t)n * 2 * SIZE_OF(f64));
+    x->tmp = ws_vec_malloc((ptrdiff_t)n * 2);
     x->gv = (f64*)CdamMallocDevice(2 * (ptrdiff_t)maxit * SIZE_OF(f64));
     x->beta = (f64*)CdamMallocDevice(((ptrdiff_t)maxit + 1) * SIZE_OF(f64));
     x->res_hist = (f64*)CdamMallocDevice(((ptrdiff_t)hist + 1) * SIZE_OF(f64));
@@ -284,6 +311,7 @@ static void ws_ensure(KrylovExt* x, index_type n, index_type maxit, index_type l
     x->d_flag = (int*)CdamMallocDevice(16);
     x->ws_n = n;
     x->ws_maxit = maxit;
+    x->ws_fresh = TRUE;
 }
 
 /* Two questions about the operands of a solve, answered with one 16-byte read: is the [begin, n) tail of b identically
@@ -317,6 +345,74 @@ static void pc_apply_fused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64*
     if (pc && pc->type == PC_ILU0) PCDILUSetActiveLength(pc, na);
     if (pc) PCApply(pc, w, z);
     else dfl_dcopy(na, w, z, DflStream());
+}
+
+/* Placement of the basis.  Measured (tools/probe_spmv_r2e.py, profiles/r02_spmv_workspace_candidates.txt): of six
+ * identical 2.3 GB basis allocations made one after the other, the FIRST one (it reuses the address range the setup
+ * temporaries were freed from) makes every SpMV of the Arnoldi loop that writes into it take 0.70 ms, the other five
+ * 0.59 ms -- a property of the allocation, stable over time, independent of where the input vector lies, and invisible to
+ * back-to-back SpMV launches (it only shows between the other kernels of the loop).  So when a new basis is allocated for a
+ * block-mode matrix, up to DFL_WS_CANDIDATES (default 4, 1 = off) candidates are allocated side by side, a short piece of
+ * the real loop (CGS over 6 columns, preconditioner, SpMV into the next column) runs in each with the SpMV timed by
+ * hipEvents on the library stream, the fastest candidate is kept and the others are freed.  A few tens of milliseconds
+ * once per work-space size; skipped when device memory is short or the basis is tiny. */
+static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_t count, index_type na, index_type m, index_type ldh) {
+    int ncand = 4;
+    const char* e = getenv("DFL_WS_CANDIDATES");
+    if (e) ncand = atoi(e);
+    if (ncand > 8) ncand = 8;
+    if (getenv("DFL_VECTOR_ARENA_GB")) ncand = 1;
+    if (ncand < 2 || ws_in_pool() || !MatrixFSBlockValues(A) || ex->has_comm || m < 8 || na < (1 << 20)) return first;
+    hipStream_t s = DflStream();
+    f64* cand[8];
+    float best_ms[8];
+    int n = 1;
+    cand[0] = first;
+    for (; n < ncand; ++n) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (size_t)count * sizeof(f64) + ((size_t)4 << 30)) break;
+        void* p = NULL;
+        if (hipMalloc(&p, (size_t)count * sizeof(f64)) != hipSuccess) { (void)hipGetLastError(); break; }
+        HIPGUARD(hipMemsetAsync(p, 0, (size_t)count * sizeof(f64), s));
+        cand[n] = (f64*)p;
+    }
+    if (n == 1) return first;
+    hipEvent_t a, b;
+    HIPGUARD(hipEventCreate(&a));
+    HIPGUARD(hipEventCreate(&b));
+    const f64 one = 1.0;
+    HIPGUARD(hipMemcpyAsync(ex->nrm, &one, sizeof one, H2D, s));
+    HIPGUARD(hipMemsetAsync(ex->H, 0, (size_t)ldh * sizeof(f64), s));
+    int best = 0;
+    for (int k = 0; k < n; ++k) {
+        f64* Q = cand[k];
+        f64 *w = Q + (size_t)6 * (size_t)na, *y = Q + (size_t)7 * (size_t)na;
+        best_ms[k] = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+            float ms = 0.f;
+            dfl_cgs_dots(na, 6, Q, na, w, ex->H, ex->work, s);
+            dfl_cgs_update(na, 6, Q, na, ex->H, w, ex->nrm + 1, 1, ex->work, s);
+            pc_apply_fused(pc, na, w, ex->nrm, ex->tmp);
+            HIPGUARD(hipEventRecord(a, s));
+            MatrixMatVec(A, ex->tmp, y);
+            HIPGUARD(hipEventRecord(b, s));
+            HIPGUARD(hipEventSynchronize(b));
+            HIPGUARD(hipEventElapsedTime(&ms, a, b));
+            if (rep > 0 && ms < best_ms[k]) best_ms[k] = ms;
+        }
+        if (best_ms[k] < best_ms[best]) best = k;
+    }
+    HIPGUARD(hipEventDestroy(a));
+    HIPGUARD(hipEventDestroy(b));
+    if (getenv("DFL_WS_VERBOSE")) {
+        fprintf(stderr, "[krylov] basis placement: in-loop SpMV into %d candidates:", n);
+        for (int k = 0; k < n; ++k) fprintf(stderr, " %.4f%s", best_ms[k], k == best ? "*" : "");
+        fprintf(stderr, " ms\n");
+    }
+    HIPGUARD(hipStreamSynchronize(s));
+    for (int k = 0; k < n; ++k)
+        if (k != best) HIPGUARD(hipFree(cand[k]));
+    return cand[best]; /* all-zero: only zero vectors went through the kernels above */
 }
 
 /* partitioned runs: the local dot products cover ghost rows too, so those must be zero in every Krylov vector (SpMV and
@@ -361,6 +457,10 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
         /* partitioned runs keep the matvec: every rank has to take the same path through the halo exchange */
         probe_operands(b, up_system ? 4 * (n / 6) : n, n, dist ? NULL : x, ex->work, &tail_zero, &x_is_zero);
         if (up_system && tail_zero) na = 4 * (n / 6);
+    }
+    if (ex->ws_fresh) {
+        ex->ws_fresh = FALSE;
+        ex->Q = ws_pick_basis(ex, A, pc, ex->Q, (ptrdiff_t)n * (m + 1), na, m, ldh);
     }
     f64* Q = ex->Q;
     f64* H = ex->H;

@@ -29,10 +29,22 @@ for i in range(5):
 big = api.DeviceArray(8 * 6 * N + 4096)
 for i in range(5, 8):
     cands.append(("slice %d of one block" % i, big.view(i * (6 * N + 512), 6 * N)))
+# the library's device pool (one 32 GiB hipMalloc made at Init): single vectors and slices of a Krylov-basis-sized block
+L.DflDeviceMalloc.restype = vp; L.DflDeviceMalloc.argtypes = [i64]
+for i in range(3):
+    cands.append(("pool vector #%d" % i, api.DeviceArray(6 * N, np.float64, ptr=L.DflDeviceMalloc(8 * 6 * N))))
+    keep.append(L.DflDeviceMalloc(8 * 1000003 * (i + 1)))
+pq = L.DflDeviceMalloc(8 * 4 * N * 42)
+for i in (0, 20, 40):
+    cands.append(("pool basis column %d" % i, api.DeviceArray(6 * N, np.float64, ptr=pq + 8 * 4 * N * i)))
+hq = api.DeviceArray(4 * N * 42)
+for i in (0, 20, 40):
+    cands.append(("hipMalloc basis column %d" % i, hq.view(4 * N * i, 4 * N)))
 t = api.Timer()
 
 
 def run(y, variant):
+    global x
     L.dfl_tune(0, variant)
     res = []
     L.dfl_bcsr_spmv(N, rp.ptr, ci.ptr, val, 1.0, x.ptr, 0.0, y.ptr, None)
