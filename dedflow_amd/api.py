@@ -241,7 +241,7 @@ class Particles:
         lib().ParticleContextDestroy(self.ctx)
 
 
-PC_DECOMPOSITION, PC_ILU0 = 0x2, 0x5   # PCType values (include/dedflow.h)
+PC_DECOMPOSITION, PC_ILU0, PC_TWOLEVEL = 0x2, 0x5, 0x6   # PCType values (include/dedflow.h)
 ALLREDUCE_FN = C.CFUNCTYPE(None, vp, vp, C.c_int32)
 HALO_FN = C.CFUNCTYPE(None, vp, vp)
 
@@ -292,6 +292,9 @@ def _declare(L):
     f("PCCreateJacobi", vp, [C.POINTER(Matrix), i32, vp]); f("PCCreateNone", vp, [C.POINTER(Matrix), i32])
     f("PCCreateDILU", vp, [C.POINTER(Matrix)]); f("PCDILUGetColors", i32, [vp, vp]); f("PCDILUGetInverseBlocks", vp, [vp])
     f("KrylovSetPCType", None, [vp, C.c_int]); f("KrylovGetPC", vp, [vp]); f("KrylovSetFusedNorm", None, [vp, C.c_int]); f("KrylovSetRestart", None, [vp, i32])
+    f("KrylovSetFlexible", None, [vp, i32]); f("KrylovSetMesh", None, [vp, C.POINTER(Mesh3D)]); f("KrylovSetAggregateSize", None, [vp, i32])
+    f("PCTwoLevelInfo", None, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_int64)]); f("PCTwoLevelAggregates", vp, [vp])
+    f("PCTwoLevelCoarseMatrix", C.POINTER(Matrix), [vp]); f("PCTwoLevelSetInner", None, [vp, i32, f64])
     f("AssembleSystemTet", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix)])
     f("AssembleSystemTetFace", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix)])
     f("AssembleSystem", None, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix), vp, i32])
@@ -360,6 +363,7 @@ class Problem:
         self.nnz1 = int(self.spy1x1.contents.nnz)
         self.ksp = L.KrylovCreateGMRES(maxit, atol, rtol, None)
         L.KrylovSetVerbose(self.ksp, 0 if quiet else 1)
+        L.KrylovSetMesh(self.ksp, self.mesh)
         if color:
             L.Mesh3DGenerateColorBatch(self.mesh)
         self.bcs = []

@@ -88,6 +88,7 @@ index_type SolveFlowSystem(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matr
     if (maxit <= 0) maxit = 4;
     FlowWork* fw = fw_get(mesh);
     const DflComm* comm = KrylovGetComm(ksp);
+    KrylovSetMesh(ksp, mesh); /* node coordinates for aggregation-based preconditioners */
     f64 *wgalpha = fw->wgalpha, *dwgalpha = fw->dwgalpha;
     alpha_states(mesh, wgold, dwgold, dwg, wgalpha, dwgalpha);
     DflAssembleSystemPrepacked(mesh, wgalpha, dwgalpha, F, NULL, bcs, nbc, TRUE);

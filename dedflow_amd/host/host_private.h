@@ -137,4 +137,6 @@ int DflVectorArenaFree(void* p);
 /* driver.c */
 index_type SolveFlowSystem(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* J, f64* F, f64* dx, Krylov* ksp,
                            Dirichlet** bcs, index_type nbc, index_type maxit, f64* rnorm_out, f64* rnorm_init_out);
+void DflKrylovSolvePrepared(Krylov* ksp, Matrix* A, f64* x, f64* b); /* KrylovSolve without PC (re)build and PCSetup */
+
 #endif

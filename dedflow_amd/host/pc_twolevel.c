@@ -1,0 +1,385 @@
+/* PC_TWOLEVEL: block-DILU smoothing + aggregation coarse-grid correction for the block-mode (u,p) matrix.
+ *
+ * Not in the reference (its only multilevel hook is the commented AMGX configuration of src/krylov.c:409-437, an
+ * AGGREGATION AMG with a MULTICOLOR_DILU smoother); BASELINE config 5 (50M tets, 100-step transient) is out of reach of
+ * one-level preconditioners: DILU-GMRES needs ~600 iterations per solve there and stalls on later steps, because the
+ * pressure part of the system is a Poisson-like problem whose conditioning grows like h^-2.  One coarse level removes that
+ * dependence (measured iteration counts: DESIGN.md section 3):
+ *
+ *     z  = S r                                  S = multicolor block-DILU (host/pc_dilu.c)
+ *     z += P Ac^-1 P^T (r - A z)                P = piecewise constant over node aggregates, Ac = P^T A P
+ *
+ * Aggregates: recursive coordinate bisection of the mesh nodes down to `agg_size` nodes (host, once per mesh + pattern).
+ * P^T A P with a piecewise-constant P is a sum of fine 4x4 blocks per coarse nonzero: host-built lists, summed on the
+ * device at every PCSetup in list order (csrc/k_amg.hip) -- deterministic.  The coarse matrix is an ordinary block-mode
+ * MatrixFS, and Ac^-1 is an inner KrylovSolve on it to rtol 0.1, so the outer solver has to be flexible (KrylovSolve
+ * switches FGMRES on when it builds this PC).  While the coarse level has more than DFL_TL_COARSEST (262144) nodes its inner
+ * solver is FGMRES preconditioned by another PCTwoLevel on the aggregate centroids (a K-cycle: a handful of inner
+ * iterations per level, every level 1/agg_size of the one above); the last level is DILU-GMRES.  With a single coarse level
+ * the inner Jacobi/DILU iteration count grows with the coarse grid and the 50M-tet case (232k aggregates) ran into its cap.
+ * No post-smoothing: a second DILU sweep after the correction (z += S (r - A z)) stalls the 50M-tet solve at 1e-3 -- the
+ * block-DILU iteration is not a convergent smoother for this stabilised (u,p) system on fine meshes, which is also why the
+ * outer count still grows slowly with the mesh (16 / 17 / 28 / 38 iterations to rtol 1e-4 at M = 60 / 119 / 160 / 203;
+ * DILU alone: 120 at M = 119, ~600 at M = 203), independent of the aggregate size (8 or 64) and of the inner tolerance.
+ * Single GPU only for now.
+ */
+#include <string.h>
+#include <omp.h>
+#include "dedflow.h"
+#include "dedflow_kernels.h"
+#include "host_private.h"
+
+typedef struct PCTwoLevel {
+    Matrix* A;
+    PC* smoother;
+    const CSRAttr* spy;          /* fine pattern the hierarchy was built for */
+    index_type N, Nc, n, n_active, agg_size;
+    index_type *d_agg;           /* [N] aggregate of every node */
+    index_type *d_aoff, *d_anode; /* aggregate -> nodes (ascending node id) */
+    CSRAttr *c1x1, *c1x1b, *c3x3, *c3x1, *c1x3; /* coarse nodal pattern, its copy for A11, expanded patterns */
+    Matrix* Ac;
+    index_type *d_goff, *d_gidx; /* coarse nonzero -> fine nonzeros (ascending) */
+    Krylov* cksp;
+    f64 *d_t, *d_rc, *d_xc;
+    index_type inner_maxit;
+    f64 inner_rtol;
+    int64_t inner_iterations;
+    const f64* xyz;              /* [N][3] host coordinates the aggregates are cut from */
+    f64* xyz_owned;              /* coarse levels own theirs (aggregate centroids) */
+    int level;
+} PCTwoLevel;
+static PC* tl_create(Matrix* mat, const f64* xyz, f64* xyz_owned, index_type agg_size, int level);
+
+/* ---- aggregation: RCB over node coordinates ------------------------------------------------------------------- */
+typedef struct { index_type lo, hi; } Range;
+typedef struct { const f64* c; index_type* idx; index_type leaf; Range* out; index_type nout, capout; } Rcb;
+
+static int key_less(const f64* c, int ax, index_type a, index_type b) {
+    f64 va = c[(size_t)a * 3 + ax], vb = c[(size_t)b * 3 + ax];
+    return va < vb || (va == vb && a < b);
+}
+static void select_kth(const f64* c, int ax, index_type* idx, index_type n, index_type k) {
+    index_type lo = 0, hi = n - 1;
+    while (lo < hi) {
+        index_type p = idx[lo + (hi - lo) / 2], i = lo, j = hi;
+        while (i <= j) {
+            while (key_less(c, ax, idx[i], p)) ++i;
+            while (key_less(c, ax, p, idx[j])) --j;
+            if (i <= j) { index_type t = idx[i]; idx[i] = idx[j]; idx[j] = t; ++i; --j; }
+        }
+        if (k <= j) hi = j; else if (k >= i) lo = i; else return;
+    }
+}
+static void rcb_emit(Rcb* x, index_type lo, index_type hi) {
+#pragma omp critical(dfl_twolevel_emit)
+    {
+        if (x->nout == x->capout) {
+            x->capout *= 2;
+            x->out = (Range*)realloc(x->out, sizeof(Range) * (size_t)x->capout);
+        }
+        x->out[x->nout].lo = lo;
+        x->out[x->nout].hi = hi;
+        x->nout++;
+    }
+}
+static void rcb_split(Rcb* x, index_type lo, index_type hi) {
+    const index_type n = hi - lo;
+    if (n <= x->leaf) { rcb_emit(x, lo, hi); return; }
+    f64 bl[3] = {1e300, 1e300, 1e300}, bh[3] = {-1e300, -1e300, -1e300};
+    for (index_type i = lo; i < hi; ++i)
+        for (int d = 0; d < 3; ++d) {
+            f64 v = x->c[(size_t)x->idx[i] * 3 + d];
+            if (v < bl[d]) bl[d] = v;
+            if (v > bh[d]) bh[d] = v;
+        }
+    int ax = 0;
+    if (bh[1] - bl[1] > bh[ax] - bl[ax]) ax = 1;
+    if (bh[2] - bl[2] > bh[ax] - bl[ax]) ax = 2;
+    const index_type half = n / 2;
+    select_kth(x->c, ax, x->idx + lo, n, half);
+    if (n > 8192) {
+#pragma omp task
+        rcb_split(x, lo, lo + half);
+#pragma omp task
+        rcb_split(x, lo + half, hi);
+#pragma omp taskwait
+    } else {
+        rcb_split(x, lo, lo + half);
+        rcb_split(x, lo + half, hi);
+    }
+}
+static int cmp_range(const void* a, const void* b) {
+    index_type x = ((const Range*)a)->lo, y = ((const Range*)b)->lo;
+    return (x > y) - (x < y);
+}
+static int cmp_i32(const void* a, const void* b) {
+    index_type x = *(const index_type*)a, y = *(const index_type*)b;
+    return (x > y) - (x < y);
+}
+
+static void tl_release(PCTwoLevel* d) {
+    CdamFreeDevice(d->d_agg, 0); CdamFreeDevice(d->d_aoff, 0); CdamFreeDevice(d->d_anode, 0);
+    CdamFreeDevice(d->d_goff, 0); CdamFreeDevice(d->d_gidx, 0);
+    CdamFreeDevice(d->d_t, 0); CdamFreeDevice(d->d_rc, 0); CdamFreeDevice(d->d_xc, 0);
+    d->d_agg = d->d_aoff = d->d_anode = d->d_goff = d->d_gidx = NULL;
+    d->d_t = d->d_rc = d->d_xc = NULL;
+    if (d->cksp) KrylovDestroy(d->cksp);
+    d->cksp = NULL;
+    if (d->Ac) MatrixDestroy(d->Ac);
+    d->Ac = NULL;
+    CSRAttrDestroy(d->c3x3); CSRAttrDestroy(d->c3x1); CSRAttrDestroy(d->c1x3); CSRAttrDestroy(d->c1x1b); CSRAttrDestroy(d->c1x1);
+    d->c3x3 = d->c3x1 = d->c1x3 = d->c1x1b = d->c1x1 = NULL;
+}
+
+/* aggregates, coarse pattern, Galerkin lists, coarse matrix + solver: once per (mesh, fine pattern) */
+static void tl_build(PCTwoLevel* d) {
+    const CSRAttr* spy = d->spy;
+    const index_type N = d->N;
+    const f64* xg = d->xyz;
+    int nt = omp_get_max_threads();
+    if (getenv("DFL_HOST_THREADS")) nt = atoi(getenv("DFL_HOST_THREADS"));
+    if (nt > 16) nt = 16;
+    if (nt < 1) nt = 1;
+    const int verbose = getenv("DFL_PATCH_VERBOSE") != NULL;
+    double t0 = omp_get_wtime();
+    index_type* rp = (index_type*)malloc(sizeof(index_type) * ((size_t)N + 1));
+    index_type* ci = (index_type*)malloc(sizeof(index_type) * (size_t)spy->nnz);
+    HIPGUARD(hipMemcpy(rp, spy->row_ptr, sizeof(index_type) * ((size_t)N + 1), D2H));
+    HIPGUARD(hipMemcpy(ci, spy->col_ind, sizeof(index_type) * (size_t)spy->nnz, D2H));
+    /* 1. aggregates */
+    index_type* idx = (index_type*)malloc(sizeof(index_type) * (size_t)N);
+    for (index_type i = 0; i < N; ++i) idx[i] = i;
+    Rcb x = {xg, idx, d->agg_size, NULL, 0, 1024};
+    x.out = (Range*)malloc(sizeof(Range) * (size_t)x.capout);
+#pragma omp parallel num_threads(nt)
+#pragma omp single
+    rcb_split(&x, 0, N);
+    qsort(x.out, (size_t)x.nout, sizeof(Range), cmp_range);
+    const index_type Nc = x.nout;
+    index_type* agg = (index_type*)malloc(sizeof(index_type) * (size_t)N);
+    index_type* aoff = (index_type*)malloc(sizeof(index_type) * ((size_t)Nc + 1));
+    for (index_type I = 0; I < Nc; ++I) {
+        aoff[I] = x.out[I].lo;
+        qsort(idx + x.out[I].lo, (size_t)(x.out[I].hi - x.out[I].lo), sizeof(index_type), cmp_i32); /* ascending node id */
+        for (index_type k = x.out[I].lo; k < x.out[I].hi; ++k) agg[idx[k]] = I;
+    }
+    aoff[Nc] = N;
+    /* 2. coarse pattern: row I = sorted unique aggregates of the neighbours of its nodes */
+    index_type* crp = (index_type*)malloc(sizeof(index_type) * ((size_t)Nc + 1));
+    index_type** rows = (index_type**)malloc(sizeof(index_type*) * (size_t)Nc);
+    index_type* rlen = (index_type*)malloc(sizeof(index_type) * (size_t)Nc);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+    for (index_type I = 0; I < Nc; ++I) {
+        size_t cap = 0;
+        for (index_type k = aoff[I]; k < aoff[I + 1]; ++k) cap += (size_t)(rp[idx[k] + 1] - rp[idx[k]]);
+        index_type* tmp = (index_type*)malloc(sizeof(index_type) * (cap > 0 ? cap : 1));
+        size_t m = 0;
+        for (index_type k = aoff[I]; k < aoff[I + 1]; ++k)
+            for (index_type z = rp[idx[k]]; z < rp[idx[k] + 1]; ++z) tmp[m++] = agg[ci[z]];
+        qsort(tmp, m, sizeof(index_type), cmp_i32);
+        index_type u = 0;
+        for (size_t q = 0; q < m; ++q)
+            if (q == 0 || tmp[q] != tmp[q - 1]) tmp[u++] = tmp[q];
+        rows[I] = tmp;
+        rlen[I] = u;
+    }
+    crp[0] = 0;
+    for (index_type I = 0; I < Nc; ++I) {
+        ASSERT((int64_t)crp[I] + rlen[I] < 2147483647LL);
+        crp[I + 1] = crp[I] + rlen[I];
+    }
+    const index_type nnzc = crp[Nc];
+    index_type* cci = (index_type*)malloc(sizeof(index_type) * (size_t)(nnzc > 0 ? nnzc : 1));
+    for (index_type I = 0; I < Nc; ++I) {
+        memcpy(cci + crp[I], rows[I], sizeof(index_type) * (size_t)rlen[I]);
+        free(rows[I]);
+    }
+    /* 3. Galerkin lists: coarse nonzero -> fine nonzeros, ascending fine index */
+    index_type* goff = (index_type*)calloc((size_t)nnzc + 1, sizeof(index_type));
+    index_type* fz2cz = (index_type*)malloc(sizeof(index_type) * (size_t)spy->nnz);
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (index_type i = 0; i < N; ++i) {
+        const index_type I = agg[i];
+        for (index_type z = rp[i]; z < rp[i + 1]; ++z) {
+            const index_type J = agg[ci[z]];
+            index_type lo = crp[I], hi = crp[I + 1] - 1;
+            while (lo < hi) {
+                index_type mid = (lo + hi) >> 1;
+                if (cci[mid] < J) lo = mid + 1; else hi = mid;
+            }
+            fz2cz[z] = lo;
+        }
+    }
+    for (index_type z = 0; z < spy->nnz; ++z) goff[fz2cz[z] + 1]++;
+    for (index_type c = 0; c < nnzc; ++c) goff[c + 1] += goff[c];
+    index_type* gidx = (index_type*)malloc(sizeof(index_type) * (size_t)spy->nnz);
+    {
+        index_type* cur = (index_type*)malloc(sizeof(index_type) * (size_t)(nnzc > 0 ? nnzc : 1));
+        memcpy(cur, goff, sizeof(index_type) * (size_t)nnzc);
+        for (index_type z = 0; z < spy->nnz; ++z) gidx[cur[fz2cz[z]]++] = z;
+        free(cur);
+    }
+    /* 4. upload; coarse matrix objects in the reference's own shapes */
+#define UP(dst, src, cnt)                                                                             \
+    dst = (index_type*)CdamMallocDevice((ptrdiff_t)((cnt) > 0 ? (cnt) : 1) * SIZE_OF(index_type));    \
+    HIPGUARD(hipMemcpy(dst, src, sizeof(index_type) * (size_t)(cnt), H2D));
+    UP(d->d_agg, agg, N) UP(d->d_aoff, aoff, Nc + 1) UP(d->d_anode, idx, N)
+    UP(d->d_goff, goff, nnzc + 1) UP(d->d_gidx, gidx, spy->nnz)
+    CSRAttr* c = (CSRAttr*)CdamMallocHost(SIZE_OF(CSRAttr));
+    memset(c, 0, sizeof *c);
+    c->num_row = c->num_col = Nc;
+    c->nnz = nnzc;
+    UP(c->row_ptr, crp, Nc + 1) UP(c->col_ind, cci, nnzc)
+#undef UP
+    d->c1x1 = c;
+    d->c3x3 = CSRAttrCreateBlock(c, 3, 3);
+    d->c3x1 = CSRAttrCreateBlock(c, 3, 1);
+    d->c1x3 = CSRAttrCreateBlock(c, 1, 3);
+    const index_type offset[] = {0, 3, 4, 5, 6};
+    d->Ac = MatrixCreateTypeFS(4, offset, NULL);
+    MatrixFS* fs = (MatrixFS*)d->Ac->data;
+    fs->spy1x1 = c;
+    fs->mat[0] = MatrixCreateTypeCSR(d->c3x3, NULL);
+    fs->mat[1] = MatrixCreateTypeCSR(d->c3x1, NULL);
+    fs->mat[4] = MatrixCreateTypeCSR(d->c1x3, NULL);
+    d->c1x1b = CSRAttrCreateBlock(c, 1, 1);
+    fs->mat[5] = MatrixCreateTypeCSR(d->c1x1b, NULL);
+    MatrixSetup(d->Ac);
+    ASSERT(MatrixFSBlockValues(d->Ac));
+    index_type coarsest = 262144;
+    if (getenv("DFL_TL_COARSEST")) coarsest = atoi(getenv("DFL_TL_COARSEST"));
+    const int recurse = Nc > coarsest && Nc * 2 < N;
+    index_type kcycle = 8;
+    if (getenv("DFL_TL_KCYCLE")) kcycle = atoi(getenv("DFL_TL_KCYCLE"));
+    if (getenv("DFL_TL_INNER_RTOL")) d->inner_rtol = atof(getenv("DFL_TL_INNER_RTOL"));
+    d->cksp = KrylovCreateGMRES(recurse ? kcycle : d->inner_maxit, 0.0, d->inner_rtol, NULL);
+    KrylovSetVerbose(d->cksp, FALSE);
+    if (recurse) {
+        f64* cx = (f64*)malloc(sizeof(f64) * 3 * (size_t)Nc);
+        for (index_type I = 0; I < Nc; ++I) {
+            f64 sx = 0, sy = 0, sz = 0;
+            for (index_type k = aoff[I]; k < aoff[I + 1]; ++k) {
+                sx += xg[(size_t)idx[k] * 3];
+                sy += xg[(size_t)idx[k] * 3 + 1];
+                sz += xg[(size_t)idx[k] * 3 + 2];
+            }
+            const f64 w = 1.0 / (f64)(aoff[I + 1] - aoff[I]);
+            cx[(size_t)I * 3] = sx * w;
+            cx[(size_t)I * 3 + 1] = sy * w;
+            cx[(size_t)I * 3 + 2] = sz * w;
+        }
+        d->cksp->pc = tl_create(d->Ac, cx, cx, d->agg_size, d->level + 1); /* destroyed with the inner solver */
+        KrylovSetFlexible(d->cksp, TRUE);
+        KrylovSetCheckInterval(d->cksp, 2);
+    } else {
+        d->cksp->pc = PCCreateDILU(d->Ac);
+        KrylovSetCheckInterval(d->cksp, 4);
+    }
+    d->Nc = Nc;
+    d->d_t = (f64*)CdamMallocDevice((ptrdiff_t)d->n * SIZE_OF(f64));
+    d->d_rc = (f64*)CdamMallocDevice((ptrdiff_t)Nc * 6 * SIZE_OF(f64));
+    d->d_xc = (f64*)CdamMallocDevice((ptrdiff_t)Nc * 6 * SIZE_OF(f64));
+    if (verbose)
+        fprintf(stderr, "[twolevel] level %d: %d nodes -> %d aggregates (<= %d nodes), coarse nnz %d (%.1f per row), %s below, %.2f s\n",
+                d->level, N, Nc, d->agg_size, nnzc, (double)nnzc / (double)(Nc > 0 ? Nc : 1), recurse ? "another level" : "DILU-GMRES",
+                omp_get_wtime() - t0);
+    free(gidx); free(fz2cz); free(goff); free(cci); free(rlen); free(rows); free(crp); free(aoff); free(agg); free(x.out); free(idx);
+    free(ci); free(rp);
+}
+
+static void tl_setup(PC* pc) {
+    PCTwoLevel* d = (PCTwoLevel*)pc->data;
+    Matrix* A = (Matrix*)pc->mat;
+    MatrixFS* fs = (MatrixFS*)A->data;
+    if (d->spy != fs->spy1x1) {
+        tl_release(d);
+        d->spy = fs->spy1x1;
+        d->N = fs->spy1x1->num_row;
+        tl_build(d);
+    }
+    PCSetup(d->smoother);
+    dfl_amg_galerkin(d->c1x1->nnz, d->d_goff, d->d_gidx, MatrixFSBlockValues(A), MatrixFSBlockValues(d->Ac), DflStream());
+    PCSetup((PC*)d->cksp->pc); /* the levels below: their coarse matrices change here, not between applications */
+}
+
+static void tl_apply(PC* pc, value_type* r, value_type* z) {
+    PCTwoLevel* d = (PCTwoLevel*)pc->data;
+    Matrix* A = (Matrix*)pc->mat;
+    hipStream_t s = DflStream();
+    const index_type N = d->N, Nc = d->Nc, n = d->n_active > 0 ? d->n_active : d->n;
+    PCDILUSetActiveLength(d->smoother, n);
+    PCApply(d->smoother, r, z);                 /* z = S r (copies the phi / T tail when n > 4N) */
+    dfl_dcopy(4 * N, r, d->d_t, s);
+    MatrixAMVPBY(A, -1.0, z, 1.0, d->d_t);      /* t = r - A z on the (u,p) part */
+    dfl_amg_restrict(Nc, d->d_aoff, d->d_anode, N, d->d_t, d->d_rc, s);
+    HIPGUARD(hipMemsetAsync(d->d_xc, 0, (size_t)Nc * 6 * sizeof(f64), s));
+    DflKrylovSolvePrepared(d->cksp, d->Ac, d->d_xc, d->d_rc); /* the phi / T tail of rc is zero: the solve runs on 4 Nc */
+    d->inner_iterations += KrylovGetStats(d->cksp)->iterations;
+    dfl_amg_prolong_add(N, d->d_agg, Nc, d->d_xc, z, s);
+}
+
+static void tl_destroy(PC* pc) {
+    PCTwoLevel* d = (PCTwoLevel*)pc->data;
+    tl_release(d);
+    PCDestroy(d->smoother);
+    free(d->xyz_owned);
+    CdamFreeHost(d, SIZE_OF(PCTwoLevel));
+}
+
+PC* PCCreateTwoLevel(Matrix* mat, const Mesh3D* mesh, index_type agg_size) {
+    if (!mat || !MatrixFSBlockValues(mat) || !mesh || !mesh->host || mesh->num_node != ((MatrixFS*)mat->data)->spy1x1->num_row) {
+        fprintf(stderr, "PCCreateTwoLevel: needs the block-mode (u,p) field-split matrix and the mesh it was built on\n");
+        return NULL;
+    }
+    if (MatrixFSOwnedRows(mat) != mesh->num_node) {
+        fprintf(stderr, "PCCreateTwoLevel: element-partitioned matrices are not supported yet\n");
+        return NULL;
+    }
+    return tl_create(mat, mesh->host->xg, NULL, agg_size, 0);
+}
+
+static PC* tl_create(Matrix* mat, const f64* xyz, f64* xyz_owned, index_type agg_size, int level) {
+    PC* pc = (PC*)CdamMallocHost(SIZE_OF(PC));
+    memset(pc, 0, sizeof *pc);
+    PCTwoLevel* d = (PCTwoLevel*)CdamMallocHost(SIZE_OF(PCTwoLevel));
+    memset(d, 0, sizeof *d);
+    d->A = mat;
+    d->xyz = xyz;
+    d->xyz_owned = xyz_owned;
+    d->level = level;
+    d->n = MatrixNumRow(mat);
+    d->agg_size = agg_size > 0 ? agg_size : 64;
+    d->inner_maxit = 40;
+    d->inner_rtol = 0.1;
+    d->smoother = PCCreateDILU(mat);
+    pc->type = PC_TWOLEVEL;
+    pc->mat = mat;
+    pc->data = d;
+    pc->op->setup = tl_setup;
+    pc->op->apply = tl_apply;
+    pc->op->destroy = tl_destroy;
+    return pc;
+}
+
+void PCTwoLevelSetActiveLength(PC* pc, index_type n_active) {
+    if (pc && pc->type == PC_TWOLEVEL) ((PCTwoLevel*)pc->data)->n_active = n_active;
+}
+void PCTwoLevelSetInner(PC* pc, index_type max_iter, f64 rtol) {
+    if (!pc || pc->type != PC_TWOLEVEL) return;
+    PCTwoLevel* d = (PCTwoLevel*)pc->data;
+    d->inner_maxit = max_iter;
+    d->inner_rtol = rtol;
+    if (d->cksp) {
+        d->cksp->max_iter = max_iter;
+        d->cksp->rtol = rtol;
+    }
+}
+void PCTwoLevelInfo(PC* pc, index_type* num_aggregate, index_type* coarse_nnz, int64_t* inner_iterations) {
+    PCTwoLevel* d = (PCTwoLevel*)pc->data;
+    if (num_aggregate) *num_aggregate = d->Nc;
+    if (coarse_nnz) *coarse_nnz = d->c1x1 ? d->c1x1->nnz : 0;
+    if (inner_iterations) *inner_iterations = d->inner_iterations;
+}
+/* introspection for tests: device pointers of the aggregate map and of the coarse block values */
+const index_type* PCTwoLevelAggregates(PC* pc) { return ((PCTwoLevel*)pc->data)->d_agg; }
+Matrix* PCTwoLevelCoarseMatrix(PC* pc) { return ((PCTwoLevel*)pc->data)->Ac; }

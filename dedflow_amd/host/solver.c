@@ -213,13 +213,16 @@ typedef struct KrylovExt {
     b32 has_comm;
     PCType pc_type; /* tree KrylovSolve builds: PC_DECOMPOSITION (reference) or PC_ILU0 */
     index_type restart; /* GMRES(m): basis columns per cycle; <= 0 or >= max_iter = full GMRES (the reference, krylov.c:56-334) */
+    b32 flexible;   /* FGMRES: keep Z[:,k] = M_k^-1 Q[:,k] (a second basis) so that the preconditioner may vary from step to step */
+    const Mesh3D* mesh; /* optional: node coordinates for preconditioners that aggregate nodes (PC_TWOLEVEL) */
+    index_type agg_size; /* PC_TWOLEVEL: nodes per aggregate */
     b32 fused_norm; /* partitioned runs: ||w - Qh|| from w.w - sum h^2, one all-reduce per Arnoldi step (off by default) */
     int* d_flag;    /* device int raised by the fused-norm kernel on heavy cancellation */
     /* cached GMRES work space */
     index_type ws_n, ws_maxit, ws_hist;
     int ws_pooled; /* where Q and tmp of the cached work space came from */
     b32 ws_fresh;  /* the basis was (re)allocated and its placement has not been calibrated yet */
-    f64 *Q, *H, *tmp, *gv, *beta, *res_hist, *nrm, *work;
+    f64 *Q, *Z, *H, *tmp, *gv, *beta, *res_hist, *nrm, *work;
     int64_t work_len;
 } KrylovExt;
 
@@ -253,6 +256,9 @@ void KrylovSetPCType(Krylov* k, PCType type) {
 PC* KrylovGetPC(const Krylov* k) { return (PC*)k->pc; }
 void KrylovSetFusedNorm(Krylov* k, b32 on) { kext(k)->fused_norm = on; }
 void KrylovSetRestart(Krylov* k, index_type m) { kext(k)->restart = m; }
+void KrylovSetFlexible(Krylov* k, b32 on) { kext(k)->flexible = on; }
+void KrylovSetMesh(Krylov* k, const Mesh3D* mesh) { kext(k)->mesh = mesh; }
+void KrylovSetAggregateSize(Krylov* k, index_type nodes) { kext(k)->agg_size = nodes; }
 const DflComm* KrylovGetComm(const Krylov* k) { return kext(k)->has_comm ? &kext(k)->comm : NULL; }
 void KrylovSetComm(Krylov* k, const DflComm* comm) {
     KrylovExt* x = kext(k);
@@ -285,11 +291,11 @@ static void ws_vec_free_as(f64* p, int pooled) {
 }
 
 static void ws_free(KrylovExt* x) {
-    ws_vec_free_as(x->Q, x->ws_pooled); CdamFreeDevice(x->H, 0); ws_vec_free_as(x->tmp, x->ws_pooled); CdamFreeDevice(x->gv, 0);
+    ws_vec_free_as(x->Q, x->ws_pooled); ws_vec_free_as(x->Z, x->ws_pooled); CdamFreeDevice(x->H, 0); ws_vec_free_as(x->tmp, x->ws_pooled); CdamFreeDevice(x->gv, 0);
     CdamFreeDevice(x->beta, 0); CdamFreeDevice(x->res_hist, 0); CdamFreeDevice(x->nrm, 0); CdamFreeDevice(x->work, 0);
     CdamFreeDevice(x->d_flag, 0);
     x->d_flag = NULL;
-    x->Q = x->H = x->tmp = x->gv = x->beta = x->res_hist = x->nrm = x->work = NULL;
+    x->Q = x->Z = x->H = x->tmp = x->gv = x->beta = x->res_hist = x->nrm = x->work = NULL;
     x->ws_n = x->ws_maxit = x->ws_hist = 0;
 }
 
@@ -343,6 +349,7 @@ static void pc_apply_fused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64*
     }
     if (d_nrm) dfl_dscal_inv_dev(na, d_nrm, w, DflStream());
     if (pc && pc->type == PC_ILU0) PCDILUSetActiveLength(pc, na);
+    if (pc && pc->type == PC_TWOLEVEL) PCTwoLevelSetActiveLength(pc, na);
     if (pc) PCApply(pc, w, z);
     else dfl_dcopy(na, w, z, DflStream());
 }
@@ -460,8 +467,11 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     }
     if (ex->ws_fresh) {
         ex->ws_fresh = FALSE;
-        ex->Q = ws_pick_basis(ex, A, pc, ex->Q, (ptrdiff_t)n * (m + 1), na, m, ldh);
+        if (!ex->flexible) ex->Q = ws_pick_basis(ex, A, pc, ex->Q, (ptrdiff_t)n * (m + 1), na, m, ldh);
     }
+    if (ex->flexible && !ex->Z) ex->Z = ws_vec_malloc((ptrdiff_t)n * m);
+    f64* const Zb = ex->flexible ? ex->Z : NULL;
+#define ZCOL(c) (Zb + (size_t)(c) * (size_t)na)
     f64* Q = ex->Q;
     f64* H = ex->H;
     f64* tmp = ex->tmp;
@@ -510,17 +520,18 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
            nrm[k] holds the norm Q[:,k] still has to be divided by */
         while (!converged && iter < m && total < maxit) {
             /* 2.0 tmp = inv(P) Q[:,iter]   2.2 Q[:,iter+1] = A tmp */
-            DFL_TIMED(DFL_TAG_PC, pc_apply_fused(pc, na, QCOL(iter), ex->nrm + iter, tmp));
+            f64* const zk = Zb ? ZCOL(iter) : tmp; /* FGMRES keeps every preconditioned vector */
+            DFL_TIMED(DFL_TAG_PC, pc_apply_fused(pc, na, QCOL(iter), ex->nrm + iter, zk));
             if (dist && split_rows) {
                 /* interior rows read no ghost entry: they run while the halo is in flight */
-                if (ex->comm.halo_begin) ex->comm.halo_begin(ex->comm.ctx, tmp);
-                else ex->comm.halo_exchange(ex->comm.ctx, tmp);
-                DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, tmp, QCOL(iter + 1), 0, n_interior));
-                if (ex->comm.halo_begin) ex->comm.halo_end(ex->comm.ctx, tmp);
-                DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, tmp, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A)));
+                if (ex->comm.halo_begin) ex->comm.halo_begin(ex->comm.ctx, zk);
+                else ex->comm.halo_exchange(ex->comm.ctx, zk);
+                DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, zk, QCOL(iter + 1), 0, n_interior));
+                if (ex->comm.halo_begin) ex->comm.halo_end(ex->comm.ctx, zk);
+                DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, zk, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A)));
             } else {
-                if (dist) ex->comm.halo_exchange(ex->comm.ctx, tmp);
-                DFL_TIMED(DFL_TAG_SPMV, MatrixMatVec(A, tmp, QCOL(iter + 1)));
+                if (dist) ex->comm.halo_exchange(ex->comm.ctx, zk);
+                DFL_TIMED(DFL_TAG_SPMV, MatrixMatVec(A, zk, QCOL(iter + 1)));
             }
             /* 3. classical Gram-Schmidt */
             if (dist && ex->fused_norm) {
@@ -563,9 +574,14 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
             /* 5.1 H y = beta   5.2 tmp = Q[:,0:iter] y   5.3 precondition   5.4 x += . */
             dfl_gmres_trsv(iter, H, ldh, ex->beta, s);
             /* column `iter` may still be un-normalised, but it is not used; columns < iter are normalised */
-            dfl_gemv_n(na, iter, Q, na, ex->beta, tmp, s);
-            pc_apply_fused(pc, na, tmp, NULL, tmp + n);
-            dfl_daxpy(na, 1.0, tmp + n, x, s);
+            if (Zb) { /* FGMRES: x += Z y */
+                dfl_gemv_n(na, iter, Zb, na, ex->beta, tmp, s);
+                dfl_daxpy(na, 1.0, tmp, x, s);
+            } else {
+                dfl_gemv_n(na, iter, Q, na, ex->beta, tmp, s);
+                pc_apply_fused(pc, na, tmp, NULL, tmp + n);
+                dfl_daxpy(na, 1.0, tmp + n, x, s);
+            }
         }
     }
     index_type nh = total < 512 ? total : 512;
@@ -583,6 +599,7 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     ex->stats.converged = converged;
 #undef QCOL
 #undef HCOL
+#undef ZCOL
 }
 
 /* Preconditioned conjugate gradients.  The reference's CGSolvePrivate is an empty stub
@@ -680,7 +697,10 @@ void KrylovSolve(Krylov* ksp, Matrix* A, f64* x, f64* b) {
     PC* pc = (PC*)ksp->pc;
     if (pc == NULL || pc->mat != A) {
         PCDestroy(pc);
-        if (kext(ksp)->pc_type == PC_ILU0 && MatrixFSBlockValues(A)) {
+        if (kext(ksp)->pc_type == PC_TWOLEVEL && MatrixFSBlockValues(A) && kext(ksp)->mesh) {
+            pc = PCCreateTwoLevel(A, kext(ksp)->mesh, kext(ksp)->agg_size);
+            kext(ksp)->flexible = TRUE; /* the coarse level is solved by an inner Krylov iteration: the PC varies */
+        } else if (kext(ksp)->pc_type == PC_ILU0 && MatrixFSBlockValues(A)) {
             pc = PCCreateDILU(A);
         } else if (A->type == MAT_TYPE_FS && ((MatrixFS*)A->data)->n_offset >= 4) {
             MatrixFS* fs = (MatrixFS*)A->data;
@@ -700,6 +720,12 @@ void KrylovSolve(Krylov* ksp, Matrix* A, f64* x, f64* b) {
         ksp->pc = pc;
     }
     PCSetup(pc);
+    DflKrylovSolvePrepared(ksp, A, x, b);
+}
+
+/* the solve alone: ksp->pc exists and has been set up for the current values of A (inner solvers of PC_TWOLEVEL, whose
+   coarse matrices change at PCSetup of the outer preconditioner only, not between applications) */
+void DflKrylovSolvePrepared(Krylov* ksp, Matrix* A, f64* x, f64* b) {
     ksp->ksp_solve(A, x, b, ksp);
     KrylovStats* st = &kext(ksp)->stats;
     st->total_solves++;

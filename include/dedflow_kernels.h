@@ -365,6 +365,16 @@ void dfl_face_sum_F(dfl_index num_node_entries, const dfl_index* fnode, const df
 void dfl_face_sum_J(dfl_index num_nz_entries, const dfl_index* fnz, const dfl_index* off, const dfl_index* ent,
                     const dfl_value* pJ, dfl_value* val, void* stream);
 
+/* ---- two-level preconditioner (csrc/k_amg.hip, host/pc_twolevel.c; build-defined): piecewise-constant aggregation.
+ *  galerkin   : coarse 4x4 blocks val_coarse[cz] = sum of val_fine[idx[off[cz] .. off[cz+1])] (list order)
+ *  restrict   : rc[I] = sum of r over the nodes anode[aoff[I] .. aoff[I+1]) of aggregate I, layouts [u: 3N | p: N]
+ *  prolong_add: z[i] += xc[agg[i]] */
+void dfl_amg_galerkin(dfl_index nnzc, const dfl_index* off, const dfl_index* idx, const dfl_value* val_fine, dfl_value* val_coarse,
+                      void* stream);
+void dfl_amg_restrict(dfl_index Nc, const dfl_index* aoff, const dfl_index* anode, dfl_index N, const dfl_value* r, dfl_value* rc,
+                      void* stream);
+void dfl_amg_prolong_add(dfl_index N, const dfl_index* agg, dfl_index Nc, const dfl_value* xc, dfl_value* z, void* stream);
+
 /* ---- DEM contact sweep (build-defined; the reference's Particle.c holds storage only)
  *  model: monodisperse spheres, linear spring-dashpot normal contact F = (kn*overlap - gamma_n*vn) n between
  *  particles and against the six walls of the unit box; uniform cell list with cell edge >= 2R:

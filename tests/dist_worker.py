@@ -164,11 +164,19 @@ def run_gpu(rank, world, M, its):
         print("HIST_DEV fused=%d max|hist-oracle|/r0 = %.3e" % (fused, np.abs(hist - histg).max() / r0g))
     xl = x_t.cpu().numpy()
     assert np.abs(xl[own4] - xg_[gidx4]).max() <= 1e-6 * np.abs(xg_).max()
+    # KrylovSolve itself clears the ghost rows of the residual (partial sums that belong to other ranks -- the local dots
+    # run over all rows): the same solve from an F whose ghost rows the caller did NOT zero gives the same history
+    P.assemble_system(Pp(wg_p), Pp(dwg_p), Pp(F_p), want_J=False)
+    assert float(F_t[3 * no:3 * n].abs().max()) > 0.0
+    x_t.zero_()
+    it2, r02, hist2, _ = P.solve(Pp(x_p), Pp(F_p))
+    torch.cuda.synchronize()
+    assert it2 == its and r02 == r0 and np.array_equal(hist2, hist), (r02, r0, np.abs(hist2 - hist).max())
     dist.barrier()
     if fused:
         st = api.lib().KrylovGetStats(P.ksp).contents
         assert not st.fused_norm_cancelled
-        assert comm.n_allreduce <= its + 2, comm.n_allreduce   # one per iteration + the initial residual
+        assert comm.n_allreduce <= 2 * (its + 2), comm.n_allreduce   # two solves: one per iteration + the initial residual each
     if rank == 0:
         print("DIST_GPU_OK", world, comm.n_allreduce, comm.n_halo)
     P.close()

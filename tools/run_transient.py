@@ -1,6 +1,6 @@
 """Transient loop in the shape of BASELINE config 5 on ONE GPU: M-cube mesh, PC_ILU0 (multicolor block-DILU) or the Jacobi tree,
 `steps` generalized-alpha time steps through DflTimeStep; prints per-step time, Newton/GMRES work and the device-memory footprint.
-  python tools/run_transient.py [M=203] [steps=5] [pc=dilu|jacobi] [newton=2] [gmres_maxit=120] [restart=0]"""
+  python tools/run_transient.py [M=203] [steps=5] [pc=dilu|jacobi|twolevel] [newton=2] [gmres_maxit=120] [restart=0]"""
 import sys, os, time, json, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,8 +20,12 @@ N = mesh.num_node
 wg[3 * N:4 * N] = 0.0
 L = api.lib()
 P = api.Problem(mesh, maxit=maxit, atol=1e-12, rtol=1e-4, quiet=True)
-L.KrylovSetPCType(P.ksp, api.PC_ILU0 if pc == "dilu" else api.PC_DECOMPOSITION)
+L.KrylovSetPCType(P.ksp, {"dilu": api.PC_ILU0, "twolevel": api.PC_TWOLEVEL}.get(pc, api.PC_DECOMPOSITION))
+if os.environ.get("DFL_AGG"):
+    L.KrylovSetAggregateSize(P.ksp, int(os.environ["DFL_AGG"]))
 L.KrylovSetRestart(P.ksp, restart)
+if os.environ.get("DFL_TRANSIENT_VERBOSE") == "1":
+    L.KrylovSetVerbose(P.ksp, 1)
 st = [api.DeviceArray.from_numpy(a) for a in (wg, 0.1 * dwg, 0.1 * dwg)]
 F, dx = api.DeviceArray(6 * N), api.DeviceArray(6 * N)
 api.sync()
