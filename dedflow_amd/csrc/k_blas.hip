@@ -324,6 +324,65 @@ __global__ __launch_bounds__(BLK) void norm_givens_kernel(int npart, const T* pa
     givens_step_block(iter, s_nrm, H, ldh, gv, beta, res_hist, s_col, s_gv);
 }
 
+// Partitioned runs with the fused norm and the Jacobi tree: the raw column hraw = [h_0 .. h_iter, w.w] is complete (all-
+// reduced) BEFORE the update, so ||w - Q h||^2 = w.w - sum h_j^2 is known up front and three launches collapse into one:
+//   cgs_update (w -= Q h)  +  gmres_givens_pythagoras (block 0, on a copy of the column in H)  +  the preconditioner
+//   application that opens the NEXT Arnoldi step (q = w / nrm stored as the new basis column, z = M^-1 q).
+// One owned node per thread (its 3 velocity rows and its pressure row); every block recomputes the norm from hraw in the
+// order of gmres_givens_pythagoras_kernel, so all blocks scale by the same bits.  Ghost rows are never touched (zero).
+__global__ __launch_bounds__(BLK) void cgs_update_pc_kernel(I nrows, I N, I ncol, const T* __restrict__ Q, long long ldq,
+                                                           const T* __restrict__ hraw, T* __restrict__ w,
+                                                           const T* __restrict__ dinv33, const T* __restrict__ dinv1,
+                                                           T* __restrict__ z, I iter, T* H, I ldh, T* gv, T* beta, T* res_hist,
+                                                           T* d_nrm, int* d_flag) {
+    __shared__ double sh[GIV_MAX + 2];
+    __shared__ double s_col[GIV_MAX], s_gv[2 * GIV_MAX];
+    __shared__ double s_nrm;
+    for (int j = threadIdx.x; j < ncol + 1 && j < GIV_MAX + 2; j += BLK) sh[j] = hraw[j];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ww = sh[ncol];
+        double hh = 0.0;
+        for (I j = 0; j < ncol; ++j) hh += sh[j] * sh[j];
+        double r = ww - hh;
+        if (r < 1e-6 * ww) {
+            if (d_flag && blockIdx.x == 0) *d_flag = 1;
+            if (r < 0.0) r = 0.0;
+        }
+        s_nrm = sqrt(r);
+    }
+    __syncthreads();
+    const double nrm = s_nrm;
+    const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+    if (i < nrows) {
+        double a0 = w[3 * i], a1 = w[3 * i + 1], a2 = w[3 * i + 2], ap = w[3LL * N + i];
+#pragma unroll 4
+        for (int j = 0; j < ncol; ++j) {
+            const double h = sh[j];
+            const T* q = Q + (long long)j * ldq;
+            a0 -= __builtin_nontemporal_load(q + 3 * i) * h;
+            a1 -= __builtin_nontemporal_load(q + 3 * i + 1) * h;
+            a2 -= __builtin_nontemporal_load(q + 3 * i + 2) * h;
+            ap -= __builtin_nontemporal_load(q + 3LL * N + i) * h;
+        }
+        const double s = 1.0 / nrm;
+        a0 *= s; a1 *= s; a2 *= s; ap *= s;
+        w[3 * i] = a0; w[3 * i + 1] = a1; w[3 * i + 2] = a2; w[3LL * N + i] = ap;
+        const T* A = dinv33 + i * 9;
+        z[3 * i + 0] = A[0] * a0 + A[3] * a1 + A[6] * a2;
+        z[3 * i + 1] = A[1] * a0 + A[4] * a1 + A[7] * a2;
+        z[3 * i + 2] = A[2] * a0 + A[5] * a1 + A[8] * a2;
+        z[3LL * N + i] = ap * dinv1[i];
+    }
+    if (blockIdx.x == 0) {  // uniform per block: the barriers inside givens_step_block are safe
+        T* col = H + (long long)iter * ldh;
+        for (int j = threadIdx.x; j < ncol; j += BLK) col[j] = sh[j];
+        if (threadIdx.x == 0) d_nrm[0] = nrm;
+        __syncthreads();
+        givens_step_block(iter, nrm, H, ldh, gv, beta, res_hist, s_col, s_gv);
+    }
+}
+
 // H[0:m,0:m] y = beta by back substitution (cublasDtrsv, krylov.c:297-301), one workgroup: column-oriented so that every
 // step is one coalesced column update (a single thread walking rows pays a dependent global load per entry: 85 us at m = 40)
 template <bool STAGED>
@@ -594,6 +653,13 @@ void dfl_gmres_givens(I iter, const T* d_nrm, T* d_H, I ldh, T* d_gv, T* d_beta,
 }
 void dfl_gmres_givens_sq(I iter, T* d_nrm_sq, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, void* stream) {
     gmres_givens_kernel<true><<<1, BLK, 0, S(stream)>>>(iter, d_nrm_sq, d_H, ldh, d_gv, d_beta, d_res_hist);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_cgs_update_pc_givens(I nrows, I N, I ncol, const T* Q, int64_t ldq, const T* d_hraw, T* w, const T* dinv33, const T* dinv1,
+                              T* z, I iter, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, T* d_nrm, int* d_flag, void* stream) {
+    if (ncol + 1 > GIV_MAX + 2 || nrows <= 0) abort();  // the caller falls back to the separate kernels beyond GIV_MAX columns
+    cgs_update_pc_kernel<<<ceil_div(nrows, BLK), BLK, 0, S(stream)>>>(nrows, N, ncol, Q, ldq, d_hraw, w, dinv33, dinv1, z, iter, d_H, ldh,
+                                                                      d_gv, d_beta, d_res_hist, d_nrm, d_flag);
     DFL_LAUNCH_CHECK();
 }
 void dfl_gmres_givens_pythagoras(I iter, T* d_nrm, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, int* d_flag, void* stream) {

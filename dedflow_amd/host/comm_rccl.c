@@ -157,8 +157,13 @@ DflRcclComm* DflRcclCommCreate(const char* id128, int rank, int world) {
     memset(c->send_count, 0, sizeof(index_type) * (size_t)world);
     memset(c->recv_count, 0, sizeof(index_type) * (size_t)world);
     HIPGUARD(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    HIPGUARD(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-    HIPGUARD(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    /* both events order work of ONE device across two of its streams (x complete -> pack; unpack -> boundary rows): no
+       system-scope fence needed -- the peers' data arrives through RCCL's own kernels -- and without it the record / wait
+       pair costs less idle time on the library stream (DFL_EVENT_SYSTEM_FENCE=1 restores the default) */
+    unsigned evflags = hipEventDisableTiming;
+    if (!(getenv("DFL_EVENT_SYSTEM_FENCE") && atoi(getenv("DFL_EVENT_SYSTEM_FENCE")))) evflags |= hipEventDisableSystemFence;
+    HIPGUARD(hipEventCreateWithFlags(&c->ev_ready, evflags));
+    HIPGUARD(hipEventCreateWithFlags(&c->ev_done, evflags));
     c->vt.allreduce_sum = rccl_allreduce;
     c->vt.halo_exchange = rccl_halo;
     c->vt.halo_begin = rccl_halo_begin;

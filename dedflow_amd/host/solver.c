@@ -218,6 +218,7 @@ typedef struct KrylovExt {
     index_type agg_size; /* PC_TWOLEVEL: nodes per aggregate */
     b32 fused_norm; /* partitioned runs: ||w - Qh|| from w.w - sum h^2, one all-reduce per Arnoldi step (off by default) */
     int* d_flag;    /* device int raised by the fused-norm kernel on heavy cancellation */
+    f64* hraw;      /* [ldh] raw CGS coefficients + w.w of the current column (fused update + PC + Givens kernel) */
     /* cached GMRES work space */
     index_type ws_n, ws_maxit, ws_hist;
     int ws_pooled; /* where Q and tmp of the cached work space came from */
@@ -294,7 +295,9 @@ static void ws_free(KrylovExt* x) {
     ws_vec_free_as(x->Q, x->ws_pooled); ws_vec_free_as(x->Z, x->ws_pooled); CdamFreeDevice(x->H, 0); ws_vec_free_as(x->tmp, x->ws_pooled); CdamFreeDevice(x->gv, 0);
     CdamFreeDevice(x->beta, 0); CdamFreeDevice(x->res_hist, 0); CdamFreeDevice(x->nrm, 0); CdamFreeDevice(x->work, 0);
     CdamFreeDevice(x->d_flag, 0);
+    CdamFreeDevice(x->hraw, 0);
     x->d_flag = NULL;
+    x->hraw = NULL;
     x->Q = x->Z = x->H = x->tmp = x->gv = x->beta = x->res_hist = x->nrm = x->work = NULL;
     x->ws_n = x->ws_maxit = x->ws_hist = 0;
 }
@@ -315,6 +318,7 @@ static void ws_ensure(KrylovExt* x, index_type n, index_type maxit, index_type l
     x->work_len = dfl_cgs_work_size(n, maxit + 1) + dfl_reduce_work_size();
     x->work = (f64*)CdamMallocDevice((ptrdiff_t)x->work_len * SIZE_OF(f64));
     x->d_flag = (int*)CdamMallocDevice(16);
+    x->hraw = (f64*)CdamMallocDevice((ptrdiff_t)(ldh + 32) * SIZE_OF(f64));
     x->ws_n = n;
     x->ws_maxit = maxit;
     x->ws_fresh = TRUE;
@@ -333,6 +337,16 @@ static void probe_operands(const f64* b, index_type begin, index_type n, const f
     HIPGUARD(hipStreamSynchronize(s));
     *tail_zero = h[0] == 0.0;
     *x_zero = x ? h[1] == 0.0 : FALSE;
+}
+
+/* the reference's tree (krylov.c:439-453) in its fused form: the two inverse-diagonal arrays, node count, owned rows */
+static b32 jacobi_tree_data(PC* pc, const f64** d33, const f64** d1, index_type* N, index_type* nrows) {
+    if (!pc || pc->type != PC_DECOMPOSITION || !decomposition_is_fused_up((PCDecomposition*)pc->data, N)) return FALSE;
+    PCDecomposition* d = (PCDecomposition*)pc->data;
+    *d33 = (const f64*)((PCJacobi*)d->pc[0]->data)->diag;
+    *d1 = (const f64*)((PCJacobi*)d->pc[1]->data)->diag;
+    *nrows = MatrixFSOwnedRows((Matrix*)pc->mat);
+    return TRUE;
 }
 
 /* z = M^{-1} (w / *d_nrm), q_out = w / *d_nrm   (d_nrm == NULL: no scaling) */
@@ -479,6 +493,12 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
 #define HCOL(c) (H + (size_t)(c) * (size_t)ldh)
     ex->stats.converged = FALSE;
     ex->stats.iterations = 0;
+    /* partitioned + fused norm + Jacobi tree on the (u,p) rows: update, Givens step and the next step's preconditioner
+       application in one launch (csrc/k_blas.hip, cgs_update_pc_kernel) */
+    const f64 *fj_d33 = NULL, *fj_d1 = NULL;
+    index_type fj_N = 0, fj_rows = 0;
+    const b32 fuse_pc = dist && ex->fused_norm && !Zb && m + 2 <= 1024 && getenv("DFL_NO_FUSED_UPDATE_PC") == NULL &&
+                        jacobi_tree_data(pc, &fj_d33, &fj_d1, &fj_N, &fj_rows) && na == 4 * fj_N && fj_rows > 0;
     for (index_type cycle = 0; !converged && total < maxit; ++cycle) {
         f64* res_hist = ex->res_hist + total; /* history of this cycle */
         index_type iter = 0;
@@ -518,10 +538,11 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
 
         /* the normalisation of Q[:,k] is folded into the preconditioner application that consumes it;
            nrm[k] holds the norm Q[:,k] still has to be divided by */
+        b32 z_ready = FALSE; /* fuse_pc: tmp already holds inv(P) Q[:,iter], written by the previous step's update */
         while (!converged && iter < m && total < maxit) {
             /* 2.0 tmp = inv(P) Q[:,iter]   2.2 Q[:,iter+1] = A tmp */
             f64* const zk = Zb ? ZCOL(iter) : tmp; /* FGMRES keeps every preconditioned vector */
-            DFL_TIMED(DFL_TAG_PC, pc_apply_fused(pc, na, QCOL(iter), ex->nrm + iter, zk));
+            if (!z_ready) DFL_TIMED(DFL_TAG_PC, pc_apply_fused(pc, na, QCOL(iter), ex->nrm + iter, zk));
             if (dist && split_rows) {
                 /* interior rows read no ghost entry: they run while the halo is in flight */
                 if (ex->comm.halo_begin) ex->comm.halo_begin(ex->comm.ctx, zk);
@@ -534,6 +555,15 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
                 DFL_TIMED(DFL_TAG_SPMV, MatrixMatVec(A, zk, QCOL(iter + 1)));
             }
             /* 3. classical Gram-Schmidt */
+            if (fuse_pc) {
+                DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 2, Q, na, QCOL(iter + 1), ex->hraw, ex->work, s));
+                ex->comm.allreduce_sum(ex->comm.ctx, ex->hraw, iter + 2);
+                DFL_TIMED(DFL_TAG_CGS_UPDATE,
+                          dfl_cgs_update_pc_givens(fj_rows, fj_N, iter + 1, Q, na, ex->hraw, QCOL(iter + 1), fj_d33, fj_d1, tmp, iter, H, ldh,
+                                                   ex->gv, ex->beta, res_hist, ex->nrm + iter + 1, ex->d_flag, s));
+                z_ready = TRUE;
+                goto arnoldi_step_done;
+            }
             if (dist && ex->fused_norm) {
                 /* w itself is column iter+1 of Q: one extra "column" of the dots gives w.w, one all-reduce carries h and w.w */
                 DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 2, Q, na, QCOL(iter + 1), HCOL(iter), ex->work, s));

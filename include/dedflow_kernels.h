@@ -104,6 +104,12 @@ void dfl_gmres_givens_sq(dfl_index iter, dfl_value* d_nrm_sq, dfl_value* d_H, df
 /* fused-norm option of partitioned runs: H[0..iter, iter] = all-reduced h, H[iter+1, iter] = all-reduced w.w from the same
  * reduction; the norm of the orthogonalised vector comes from w.w - sum h_j^2 (written to *d_nrm); *d_flag (int, may be
  * NULL) is raised when cancellation leaves less than 1e-6 of w.w */
+/* partitioned runs, fused norm + Jacobi tree: w -= Q h, the Pythagorean norm and Givens step of column `iter` (d_hraw =
+ * [h_0..h_iter, w.w] all-reduced, copied into H), q = w / nrm in place and z = M^-1 q for the next Arnoldi step: one launch */
+void dfl_cgs_update_pc_givens(dfl_index nrows, dfl_index N, dfl_index ncol, const dfl_value* Q, int64_t ldq, const dfl_value* d_hraw,
+                              dfl_value* w, const dfl_value* dinv33, const dfl_value* dinv1, dfl_value* z, dfl_index iter,
+                              dfl_value* d_H, dfl_index ldh, dfl_value* d_gv, dfl_value* d_beta, dfl_value* d_res_hist,
+                              dfl_value* d_nrm, int* d_flag, void* stream);
 void dfl_gmres_givens_pythagoras(dfl_index iter, dfl_value* d_nrm, dfl_value* d_H, dfl_index ldh, dfl_value* d_gv,
                                  dfl_value* d_beta, dfl_value* d_res_hist, int* d_flag, void* stream);
 /* back substitution H[0:m,0:m] y = beta[0:m] in place on beta (cublasDtrsv, krylov.c:297-301) */

@@ -48,12 +48,16 @@ for r in (0, parts // 2):
         P.assemble_system(Pp(wg_p), Pp(dwg_p), None, want_J=True)
         F_t[3 * no:3 * n].zero_(); F_t[3 * n + no:4 * n].zero_(); x_t.zero_()
         return P.solve(Pp(x_p), Pp(F_p))
-    for _ in range(2): step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    K = 5
-    for _ in range(K): step()
-    torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0) / K
+    for _ in range(3): step()
+    K = 10
+    batches = []
+    for _ in range(5):   # 5 batches of 10 steps: the median batch is reported, the spread beside it
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(K): step()
+        torch.cuda.synchronize(); batches.append(1e3 * (time.perf_counter() - t0) / K)
+    ms = float(np.median(batches))
     print("rank %d of %d: %d local tets (%d owned nodes, %d interior), %d collectives/step on a 1-rank communicator: %.2f ms per step"
-          % (r, parts, P.T, no, lm.n_interior, (comm.n_allreduce + comm.n_halo) // (K + 2), ms), flush=True)
+          % (r, parts, P.T, no, lm.n_interior, (comm.n_allreduce + comm.n_halo) // (5 * K + 3), ms) +
+          " (batches %s)" % ", ".join("%.2f" % b for b in batches), flush=True)
     P.close()
 dist.destroy_process_group()
