@@ -371,8 +371,8 @@ PC* PCCreateNone(Matrix* mat, index_type n);
 PC* PCCreateJacobi(Matrix* mat, index_type bs, void* handle);
 PC* PCCreateDecomposition(Matrix* mat, index_type n, const index_type* offset, void* handle);
 PC* PCCreateAMGX(Matrix* mat, void* options); /* returns NULL: NVIDIA-only external library (pc.c:300-304) */
-/* PC_ILU0: multicolor block-DILU on the block-mode (u,p) matrix (host/pc_dilu.c, csrc/k_dilu.hip); build-defined,
- * the reference only declares the enum value.  KrylovSetPCType(ksp, PC_ILU0) makes KrylovSolve build it instead
+/* PC_ILU0: multicolor block-DILU on the block-mode (u,p) matrix (host/pc_dilu.c, csrc/k_dilu.hip); build-defined:
+ * the reference's PCType ends at PC_CUSTOM = 0x4 (pc.h:15-21); 0x5 and 0x6 are this build's additions.  KrylovSetPCType(ksp, PC_ILU0) makes KrylovSolve build it instead
  * of the reference's Jacobi tree (PC_DECOMPOSITION = the reference default). */
 PC* PCCreateDILU(Matrix* mat);
 void PCDILUSetActiveLength(PC* pc, index_type n_active);
