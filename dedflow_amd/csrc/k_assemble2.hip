@@ -318,6 +318,314 @@ __global__ __launch_bounds__(256) void tet_rhs_wave_kernel(I P, const I* __restr
     }
 }
 
+
+// ====================================================================================
+//  Residual, lane-per-tet form (schedule 4 with 64-tet patches).  One WAVE owns a padded patch of <= 64 tets / <= NODES
+//  nodes and ONE LANE a tet: for a linear tet only the values at the quadrature point change from point to point --
+//  geometry, gradients and the vertex sums are computed once per tet instead of once per (tet, point) lane as in the
+//  4-lanes-per-tet kernels -- and the sum over the four points of shl(a,q) X(q) + shg[a].Y(q) (assemble.cu:761-924)
+//  collapses to  SHB sum_q X(q) + (SHA-SHB) X(a) + shg[a].sum_q Y(q).  Same terms as rhs_quad, different association.
+//  The waves are PERSISTENT and software-pipelined: while patch p is computed from LDS, the node records of patch p+1
+//  are in flight into registers (its node ids were loaded one patch earlier) and the index lists of patch p+2 are
+//  requested, so neither hop of the dependent chain (lists -> node ids -> records) is waited for.  The LDS slice of a wave
+//  holds the node records during the element pass and is reused for the per-(tet, vertex) results of the ordered sum.
+// ====================================================================================
+struct LaneLists {
+    int c, nid;   // requested two patches ahead (the node ids feed the record gather of the next patch)
+    unsigned ln;  // 4 local node ids of this lane's tet, one byte each; this and the rest: one patch ahead
+    uint2 adj2;
+    unsigned st0, st1;
+};
+
+// every load unconditional (padded layout: all addresses valid) so that the compiler can count the loads in flight exactly
+template <int NODES, bool HEAD_ONLY>
+__device__ __forceinline__ LaneLists lane_load_lists(int pp, int lane, const I* __restrict__ cnt, const I* __restrict__ pnode,
+                                                     const unsigned char* __restrict__ lien, const unsigned short* __restrict__ adj,
+                                                     const unsigned short* __restrict__ adj_start) {
+    static_assert(NODES == 64, "one node id per lane");
+    LaneLists L;
+    L.c = cnt[pp];
+    L.nid = pnode[(long long)pp * NODES + lane];
+    if (HEAD_ONLY) return L;
+    L.ln = reinterpret_cast<const unsigned*>(lien)[(long long)pp * 64 + lane];
+    L.adj2 = reinterpret_cast<const uint2*>(adj + (long long)pp * 256)[lane];
+    const unsigned short* st = adj_start + (long long)pp * (NODES + 1);
+    L.st0 = st[lane];
+    L.st1 = st[NODES];  // the last entry, same address for every lane
+    return L;
+}
+
+// PROBE (developer phase split under dfl_tune_asm): bit 128 skip the element pass, 256 skip the ordered sum, 512 skip the
+// record gather, 1024 skip the stores; the shipped instantiation carries none of these branches
+template <int NODES, int WPS, bool PROBE>  // WPS = waves per SIMD the registers are budgeted for (1: no spills; 2: 256 VGPRs)
+__global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __restrict__ cnt, const I* __restrict__ pnode,
+                                                             const unsigned char* __restrict__ lien,
+                                                             const unsigned short* __restrict__ adj,
+                                                             const unsigned short* __restrict__ adj_start,
+                                                             const T* __restrict__ nodep, T* __restrict__ partial, int dbg_in) {
+    const int dbg = PROBE ? dbg_in : 0;
+    constexpr int RS = NV + 1;                 // padded node record in LDS
+    constexpr int NJ = (NODES * 7 + 63) / 64;  // 16-byte pieces of the node records per lane
+    constexpr int BUF = NODES * RS > 6 * 256 ? NODES * RS : 6 * 256;
+    __shared__ __attribute__((aligned(16))) double s_buf[4][BUF];
+    __shared__ __attribute__((aligned(16))) unsigned short s_adj[4][256 + 8];  // + 8: the 4-entry reads may run past a list
+    __shared__ unsigned short s_st[4][NODES + 2];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // w in an SGPR: patch ids,
+                                                                                              // LDS bases scalar
+    // XCD-aware persistent ranges: workgroup b runs on XCD b % 8; every XCD walks one contiguous range of patches
+    const int per = (P + 7) >> 3;
+    const int pbeg = (blockIdx.x & 7) * per;
+    const int pend = min((int)P, pbeg + per);
+    const int wx = (gridDim.x >> 3) * 4;  // waves per XCD
+    int p = pbeg + (blockIdx.x >> 3) * 4 + w;
+    if (p >= pend) return;  // whole waves leave; nothing below synchronises across waves
+    double* const sb = s_buf[w];
+
+    // the pieces of the node records this lane fetches: piece k = j * 64 + lane of node k / 7
+    double2 rv[NJ];
+#define G_LN(j) ((j * 64 + lane) / 7)
+#define G_PART(j) ((j * 64 + lane) - 7 * G_LN(j))
+    auto gather = [&](int nid) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int node = __shfl(nid, G_LN(j) & 63, WAVE);  // executed by every lane
+            node = node < 0 ? 0 : node;                  // padding entries fetch record 0 (never staged): every load is issued
+            if (PROBE && (dbg & 512)) rv[j] = make_double2(1.0 + node, 2.0);
+            else rv[j] = reinterpret_cast<const double2*>(nodep + (long long)node * NREC)[G_PART(j)];
+        }
+    };
+    auto stage = [&](const LaneLists& L) {  // registers -> the wave's LDS slice
+        const int nn = L.c >> 16;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (G_LN(j) < nn) {
+                sb[G_LN(j) * RS + 2 * G_PART(j)] = rv[j].x;
+                sb[G_LN(j) * RS + 2 * G_PART(j) + 1] = rv[j].y;
+            }
+        reinterpret_cast<uint2*>(s_adj[w])[lane] = L.adj2;
+        s_st[w][lane] = (unsigned short)L.st0;
+        if (lane == 0) s_st[w][NODES] = (unsigned short)L.st1;
+    };
+
+    LaneLists L1 = lane_load_lists<NODES, false>(p, lane, cnt, pnode, lien, adj, adj_start);
+    gather(L1.nid);
+    int pn = p + wx;
+    bool has_n = pn < pend;
+    LaneLists L2 = lane_load_lists<NODES, true>(min(pn, pend - 1), lane, cnt, pnode, lien, adj, adj_start);
+    stage(L1);
+    // the head of the second patch's lists is complete before the loop is entered: inside the loop the same registers
+    // are waited for with the stores of the previous patch still in flight, and the compiler merges the two states
+    asm volatile("" ::"v"(L2.c), "v"(L2.nid));
+
+    for (;;) {
+        const int ne = L1.c & 0xffff, nn = L1.c >> 16;
+        const long long n0 = (long long)p * NODES;
+        // hop 2 of the next patch and hop 1 of the one after it: in flight during the element pass
+        WAVE_SYNC();
+
+        double out[24];  // out[a * 6 + j]
+        if (PROBE && (dbg & 128)) {
+#pragma unroll
+            for (int k = 0; k < 24; ++k) out[k] = sb[(lane + k) & 63];
+        } else if (lane < ne) {
+            const double* r[4] = {sb + (L1.ln & 255u) * RS, sb + ((L1.ln >> 8) & 255u) * RS, sb + ((L1.ln >> 16) & 255u) * RS,
+                                  sb + (L1.ln >> 24) * RS};
+            double shg[12], detJ, gg, itr;
+            {
+                double x[12], invJ[9], G[9];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) x[b * 3 + d] = r[b][d];
+                tet_geometry(x, invJ, detJ, shg);
+                tet_metric(shg, G);
+                gg = 0.0;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) gg += G[k] * G[k];
+                itr = 1.0 / (G[0] + G[4] + G[8]);
+            }
+            const double DS = SHA - SHB;
+            const double fb[3] = {FB0, FB1, FB2};
+            const double mu = kMU / kRHO, kappa = kKAPPA / (kRHO * kCP);
+            const double t0 = 4.0 / (kDT * kDT);
+            const double wq = GW * detJ;
+            double Su[3] = {0.0, 0.0, 0.0};  // vertex sums of u: both passes
+            // ---- pass 1: momentum + continuity rows.  out[a*6+j] first collects (SHA-SHB) X_j(a) (the point q = a), then
+            // takes SHB sum_q X_j + shg[a].sum_q Y_j
+            {
+                double grad[12], Sp = 0.0, Sd[3] = {0.0, 0.0, 0.0};  // gradients of u0 u1 u2 p: the same at every point
+#pragma unroll
+                for (int k = 0; k < 12; ++k) grad[k] = 0.0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double v[4] = {r[b][3], r[b][4], r[b][5], r[b][11]};
+#pragma unroll
+                    for (int comp = 0; comp < 4; ++comp)
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) grad[d + 3 * comp] += shg[d + 3 * b] * v[comp];
+                    Su[0] += v[0]; Su[1] += v[1]; Su[2] += v[2]; Sp += v[3];
+                    Sd[0] += r[b][8]; Sd[1] += r[b][9]; Sd[2] += r[b][10];
+                }
+                const double divu = grad[0] + grad[4] + grad[8];
+                double SY[12], SX[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < 12; ++k) SY[k] = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double uadv[3], qd[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        uadv[i] = SHB * Su[i] + DS * r[q][3 + i];
+                        qd[i] = SHB * Sd[i] + DS * r[q][8 + i];
+                    }
+                    const double pq = SHB * Sp + DS * r[q][11];
+                    double rLi[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        rLi[i] = kRHO * (qd[i] - fb[i]) + kRHO * uadv[0] * grad[3 * i] + kRHO * uadv[1] * grad[3 * i + 1] +
+                                 kRHO * uadv[2] * grad[3 * i + 2] + grad[9 + i];
+                    double t1 = 0.0;
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) {
+                        const double v = shg[3 + rr] * uadv[0] + shg[6 + rr] * uadv[1] + shg[9 + rr] * uadv[2];
+                        t1 += v * v;
+                    }
+                    const double y = t1 + 3.0 * mu * mu * gg;
+                    const double tau0 = rsqrt(t0 + y) * (1.0 / kRHO);
+                    const double tau1 = y * rsqrt(y) * itr;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const double xi = kRHO * (qd[i] - fb[i]) + kRHO * (uadv[0] - tau0 * rLi[0]) * grad[3 * i] +
+                                          kRHO * (uadv[1] - tau0 * rLi[1]) * grad[3 * i + 1] +
+                                          kRHO * (uadv[2] - tau0 * rLi[2]) * grad[3 * i + 2];
+                        SX[i] += xi;
+                        out[q * 6 + i] = DS * xi;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            SY[3 * i + j] += kMU * (grad[3 * i + j] + grad[3 * j + i]) + kRHO * tau0 * rLi[i] * uadv[j] -
+                                             kRHO * tau0 * tau0 * rLi[i] * rLi[j];
+                        SY[3 * i + i] += -pq + kRHO * tau1 * divu;
+                        SY[9 + i] += tau0 * rLi[i];
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double xs = j == 3 ? divu : SHB * SX[j] + out[a * 6 + j];  // X_3 = div u at every point
+                        out[a * 6 + j] = wq * (xs + shg[a * 3] * SY[3 * j] + shg[a * 3 + 1] * SY[3 * j + 1] + shg[a * 3 + 2] * SY[3 * j + 2]);
+                    }
+            }
+            // ---- pass 2: phi and T rows (u at the points and |J^-1 u|^2 recomputed: cheaper than keeping them)
+            {
+                double grad[6], Sd[2] = {0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) grad[k] = 0.0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double v[2] = {r[b][6], r[b][7]};
+#pragma unroll
+                    for (int comp = 0; comp < 2; ++comp)
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) grad[d + 3 * comp] += shg[d + 3 * b] * v[comp];
+                    Sd[0] += r[b][12]; Sd[1] += r[b][13];
+                }
+                double SY[6], SX[2] = {0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) SY[k] = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double uadv[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) uadv[i] = SHB * Su[i] + DS * r[q][3 + i];
+                    const double dphi = SHB * Sd[0] + DS * r[q][12], dT = SHB * Sd[1] + DS * r[q][13];
+                    double t1 = 0.0;
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) {
+                        const double v = shg[3 + rr] * uadv[0] + shg[6 + rr] * uadv[1] + shg[9 + rr] * uadv[2];
+                        t1 += v * v;
+                    }
+                    const double tau2 = rsqrt(t0 + t1);
+                    const double tau3 = rsqrt(t0 + t1 + 3.0 * kappa * kappa * gg) * (1.0 / (kRHO * kCP));
+                    const double bp = dphi + uadv[0] * grad[0] + uadv[1] * grad[1] + uadv[2] * grad[2];
+                    const double btc = kRHO * kCP * (dT + uadv[0] * grad[3] + uadv[1] * grad[4] + uadv[2] * grad[5]);
+                    SX[0] += bp;
+                    SX[1] += btc;
+                    out[q * 6 + 4] = DS * bp;
+                    out[q * 6 + 5] = DS * btc;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        SY[i] += bp * tau2 * uadv[i];
+                        SY[3 + i] += btc * (kRHO * kCP * tau3) * uadv[i] + kKAPPA * grad[3 + i];
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        out[a * 6 + 4 + j] = wq * (SHB * SX[j] + out[a * 6 + 4 + j] + shg[a * 3] * SY[3 * j] + shg[a * 3 + 1] * SY[3 * j + 1] +
+                                                   shg[a * 3 + 2] * SY[3 * j + 2]);
+            }
+        }
+        // hop 2 of the next patch and hop 1 of the one after it, requested AFTER the element pass (their 40 registers are
+        // free again) and in flight during the ordered sum; past the end of the range the loads are repeated on the last
+        // patch and dropped: no branch around a load
+        gather(L2.nid);
+        const int pnn = pn + wx;
+        const bool has_nn = pnn < pend;
+        {
+            const LaneLists T2 = lane_load_lists<NODES, false>(min(pn, pend - 1), lane, cnt, pnode, lien, adj, adj_start);
+            L2.ln = T2.ln; L2.adj2 = T2.adj2; L2.st0 = T2.st0; L2.st1 = T2.st1;  // (c and nid are re-read: same values)
+        }
+        const LaneLists L3 = lane_load_lists<NODES, true>(min(pnn, pend - 1), lane, cnt, pnode, lien, adj, adj_start);
+        WAVE_SYNC();  // every lane is done with the node records: the slice now takes the per-(tet, vertex) results
+        if (lane < ne) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double2* dst = reinterpret_cast<double2*>(sb + j * 256 + lane * 4);
+                dst[0] = make_double2(out[j], out[6 + j]);
+                dst[1] = make_double2(out[12 + j], out[18 + j]);
+            }
+        }
+        WAVE_SYNC();
+        // ordered sum per patch node: contributions in ascending local tet order
+        // (all NODES * 6 entries of the padded partial block are written, the unused ones as zeros: a fixed number of
+        // unconditional stores per lane, so that waiting for the loads above never waits for these stores)
+#pragma unroll
+        for (int i = 0; i < NODES * 6 / 64; ++i) {
+            const int k = lane + 64 * i;
+            const int ln = k / 6, j = k - ln * 6;
+            double sum = 0.0;
+            if (PROBE && (dbg & 256)) sum = sb[k];
+            else if (ln < nn) {
+                // four list entries per trip, all their LDS reads in flight together; the additions stay in list order
+                // (a walk of one entry per trip pays two dependent LDS latencies per entry: it dominated the kernel)
+                const int q1 = s_st[w][ln + 1];
+                for (int q = s_st[w][ln]; q < q1; q += 4) {
+                    const int i0 = s_adj[w][q], i1 = s_adj[w][q + 1] & 255, i2 = s_adj[w][q + 2] & 255, i3 = s_adj[w][q + 3] & 255;  // past the list: any valid slot
+                    const double v0 = sb[j * 256 + i0], v1 = sb[j * 256 + i1], v2 = sb[j * 256 + i2], v3 = sb[j * 256 + i3];
+                    sum += v0;
+                    if (q + 1 < q1) sum += v1;
+                    if (q + 2 < q1) sum += v2;
+                    if (q + 3 < q1) sum += v3;
+                }
+            }
+            if (!(PROBE && (dbg & 1024))) partial[n0 * 6 + k] = sum;
+            else if (sum == 1.2345e300) partial[0] = sum;
+        }
+        if (!has_n) break;
+        WAVE_SYNC();  // the sums are read: the slice and the lists take the next patch
+        L1 = L2;
+        stage(L1);
+        p = pn;
+        pn = pnn;
+        L2 = L3;
+        has_n = has_nn;
+    }
+#undef G_LN
+#undef G_PART
+}
+
 }  // namespace
 
 extern "C" {
@@ -326,6 +634,7 @@ int dfl_lhs_slot_record_bytes(void) { return SP_RS * (int)sizeof(double); }
 int64_t dfl_lhs_slot_lds_bytes(I max_tets, I max_slots, I max_contrib) { return (int64_t)slot_lds_bytes(max_tets, max_slots, max_contrib); }
 
 extern int g_patch_dbg;
+int g_rhs_lane_grid_cap = 0;  // developer / test knob (dfl_tune(2, n)): few workgroups make a small mesh walk the pipelined loop
 void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const I* ptet_ien, const I* slot_nz, const I* coff,
                                const unsigned short* desc, const T* nodep, T* val, T beta, I max_tets, I max_slots,
                                I max_contrib, void* stream) {
@@ -381,7 +690,28 @@ void dfl_assemble_tet_rhs_wave(I npatch, I pad_tets, I pad_nodes, const I* cnt, 
     const int grid = 8 * (per / 4);
     if (pad_tets == 32 && pad_nodes == 48)
         tet_rhs_wave_kernel<32, 48><<<grid, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial);
-    else if (pad_tets == 64 && pad_nodes == 64)
+    else if (pad_tets == 64 && pad_nodes == 64 && !(g_patch_dbg & 32)) {
+        // lane-per-tet kernel, persistent waves: 2 workgroups per CU (built for 2 waves per SIMD; measured 0.89 ms at 10M tets
+        // against 1.07 ms for the 1-wave build and 1.29 ms for the 4-lanes-per-tet wave kernel)
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            DFL_GUARD(hipGetDevice(&dev));
+            DFL_GUARD(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            if (cus < 8) cus = 8;
+        }
+        const int wps = (g_patch_dbg & 64) ? 1 : 2;  // developer A/B: bit 64 = the 1-wave-per-SIMD build (no spills, 512 registers)
+        int g = (wps * cus) / 8 * 8;
+        const int need = 8 * ((((npatch + 7) / 8) + 3) / 4);  // one wave per patch of an XCD's share
+        if (g > need) g = need;
+        if (g_rhs_lane_grid_cap > 0 && g > g_rhs_lane_grid_cap) g = (g_rhs_lane_grid_cap + 7) / 8 * 8;
+        if (g_patch_dbg & ~(64 | 32))
+            tet_rhs_lane_kernel<64, 1, true><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial, g_patch_dbg);
+        else if (wps == 2)
+            tet_rhs_lane_kernel<64, 2, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial, 0);
+        else
+            tet_rhs_lane_kernel<64, 1, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial, 0);
+    } else if (pad_tets == 64 && pad_nodes == 64)
         tet_rhs_wave_kernel<64, 64><<<grid, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial);
     else if (pad_tets == 16 && pad_nodes == 32)
         tet_rhs_wave_kernel<16, 32><<<grid, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial);

@@ -637,9 +637,11 @@ void dfl_bcsr_zero_scalar_rows(I N, const I* rp, const I* ci, T* val, I n, const
     DFL_LAUNCH_CHECK();
 }
 /* kernel-variant selection for A/B measurements (key 0: block-CSR SpMV variant 0..4; 4 = default, XCD-aware row slabs) */
+extern int g_rhs_lane_grid_cap;
 void dfl_tune(int key, int value) {
     if (key == 0) g_spmv_variant = value;
     if (key == 1) g_pc_apply_mode = value;
+    if (key == 2) g_rhs_lane_grid_cap = value;  // workgroups of the persistent residual kernel (0 = as many as are resident)
 }
 void dfl_bcsr_spmv(I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
     dfl_bcsr_spmv_rows(N, N, rp, ci, val, alpha, x, beta, y, stream);

@@ -462,15 +462,21 @@ def test_two_problems_with_different_configurations_coexist(api, oracle_lib):
 
 def test_wave_residual_is_reproducible_and_shape_independent(api, oracle_lib):
     """Schedule 4 assembles F with one wave per spatial patch (padded layout, no workgroup barriers): bitwise equal run to
-    run, equal to the oracle within the parity bar for every supported patch shape."""
-    m = kuhn_cube(7, jitter=0.2)
+    run, equal to the oracle within the parity bar for every supported patch shape and kernel build -- the default
+    lane-per-tet kernel on 64-tet patches (2 waves per SIMD), its 1-wave build (dfl_tune_asm 64), the 4-lanes-per-tet wave
+    kernel on the same patches (32) and on the smaller shapes.  dfl_tune(2, 8) caps the persistent kernel at 8 workgroups so
+    that every wave walks several patches through the pipelined loop (prefetch of the next patch's records and lists)."""
+    m = kuhn_cube(12, jitter=0.2)   # 10368 tets = 162 full patches of 64 on 32 persistent waves
     S = oracle_lib.System(m)
     wg, dwg = synthetic_fields(m)
     F, _ = S.assemble_system(wg, dwg, True, False)
     L = api.lib()
+    L.dfl_tune.argtypes = [C.c_int, C.c_int]
     try:
-        for tets, nodes in ((32, 48), (16, 32), (64, 64)):
+        for tets, nodes, bits, cap in ((64, 64, 0, 8), (64, 64, 0, 0), (64, 64, 64, 8), (64, 64, 32, 0), (32, 48, 0, 0), (16, 32, 0, 0)):
             L.DflSetRhsWaveParameters(tets, nodes)
+            L.dfl_tune_asm(bits)
+            L.dfl_tune(2, cap)
             P = api.Problem(m, schedule=4)
             try:
                 wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
@@ -482,11 +488,13 @@ def test_wave_residual_is_reproducible_and_shape_independent(api, oracle_lib):
                     runs.append(F_d.numpy().copy())
                 assert np.array_equal(runs[0], runs[1])
                 ok, err = close(runs[0], F)
-                assert ok, (tets, nodes, err)
+                assert ok, (tets, nodes, bits, cap, err)
             finally:
                 P.close()
     finally:
-        L.DflSetRhsWaveParameters(32, 48)
+        L.DflSetRhsWaveParameters(64, 64)
+        L.dfl_tune_asm(0)
+        L.dfl_tune(2, 0)
 
 
 def test_geometry_cache_follows_moved_nodes(api, oracle_lib):

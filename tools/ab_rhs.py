@@ -10,7 +10,7 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 119
 def parse(c):
     if c.startswith("w:"):
         v = [int(k) for k in c[2:].split(":")]
-        return (4, v[0], v[1], 0)
+        return (4, v[0], v[1], v[2] if len(v) > 2 else 0)   # w:tets:nodes[:dfl_tune_asm bits] (64:64 -> lane-per-tet kernel; 32 = the 4-lane wave kernel, 64 = 2 waves/SIMD build)
     v = [int(k) for k in c.split(":")]
     return (3, v[0], v[1], v[2] if len(v) > 2 else 0)
 cfgs = [(1, 0, 0, 0)] + [parse(c) for c in (sys.argv[2:] or ["64:64", "w:32:48", "w:64:64", "w:16:32"])]
