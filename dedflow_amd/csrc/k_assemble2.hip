@@ -138,29 +138,41 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, 
     for (;;) {
         const bool has_next = pn < pend;
         const int nt = h.y, ns = h.w;
-        // (a) hop 2 for the next patch: connectivity of this lane's tet + the three lists, into registers
-        int4 ndn = zero4;
-        int n_c = 0, n_z = 0;
-        uint2 n_d0 = make_uint2(0, 0), n_d1 = make_uint2(0, 0);
-        int pnn = pn + g8;
+        // (a) hop 2 for the next patch: connectivity of this lane's tet + the three lists, into registers.  Every load is
+        // unconditional (indices clamped into the patch; past the last patch the header is all zero and patch 0's first
+        // entries are read and dropped) and nothing is computed from the results here: the wave goes on to phase 1 with
+        // all of them in flight, and they are consumed right after phase 1 -- BEFORE this patch's row stores are issued,
+        // so that waiting for them never waits for a store
+        const int pnn = pn + g8;
         int4 hnn = zero4, hnn2 = zero4;
-        if (has_next) {
-            if (t < hn.y) ndn = ptet_ien[hn.x + t];
-            if (t <= hn.w) n_c = coff[hn.z + t] - hn2.x;
-            if (t < hn.w) n_z = slot_nz[hn.z + t];
-            const uint2* src = reinterpret_cast<const uint2*>(desc + hn2.x);
-            const int nq = (hn2.y + 3) >> 2;
-            if (t < nq) n_d0 = src[t];
-            if (t + SBLK < nq) n_d1 = src[t + SBLK];
-            if (pnn < pend) { hnn = hdr[2 * pnn]; hnn2 = hdr[2 * pnn + 1]; }
-        }
+        if (has_next && pnn < pend) { hnn = hdr[2 * pnn]; hnn2 = hdr[2 * pnn + 1]; }
+        const int nqn = (hn2.y + 3) >> 2;
+        const uint2* srcn = reinterpret_cast<const uint2*>(desc + hn2.x);
+        const int4 ndn = ptet_ien[hn.x + max(0, min(t, hn.y - 1))];
+        const int n_c = coff[hn.z + min(t, hn.w)];
+        const int n_z = slot_nz[hn.z + max(0, min(t, hn.w - 1))];
+        const uint2 n_d0 = srcn[max(0, min(t, nqn - 1))];
+        const uint2 n_d1 = srcn[max(0, min(t + SBLK, nqn - 1))];
         // (b) phase 1: one lane per (patch, tet); the records were requested one patch ago
         if (t < nt && !(dbg & 2)) {
             if (!EARLY) slot_load_records(nodep, nd, r);
             slot_tet_record(r, s_tet + t * SP_RS);
         }
         __syncthreads();
-        // (c) hop 3 for the next patch: its node records fly during phase 2
+        // (c) the lists of the next patch go into the other buffer (nobody reads it any more: the previous patch's phase 2
+        // ended before the barrier that closed the last trip; it is read after the barrier that follows the next phase 1)
+        if (has_next) {
+            char* nb = s_lists + (buf ^ 1) * lbytes;
+            int* lc = reinterpret_cast<int*>(nb);
+            int* lz = lc + max_slots + 1;
+            uint2* ld = reinterpret_cast<uint2*>(nb + desc_off);
+            if (t <= hn.w) lc[t] = n_c - hn2.x;
+            if (t < hn.w) lz[t] = n_z;
+            if (t < nqn) ld[t] = n_d0;
+            if (t + SBLK < nqn) ld[t + SBLK] = n_d1;
+        }
+        asm volatile("" ::"v"(ndn.x), "v"(ndn.y), "v"(ndn.z), "v"(ndn.w));  // the connectivity has arrived, too
+        // hop 3 for the next patch (EARLY only): its node records fly during phase 2
         if (EARLY && has_next && t < hn.y) slot_load_records(nodep, ndn, r);
 
         // ---- phase 2: one lane quad per slot ---------------------------------------------------------------------
@@ -231,18 +243,6 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, 
         }
         if (!has_next) break;
         nd = ndn;
-        // (e) the lists of the next patch go into the other buffer (read after the barrier that follows its phase 1)
-        {
-            char* nb = s_lists + (buf ^ 1) * lbytes;
-            int* lc = reinterpret_cast<int*>(nb);
-            int* lz = lc + max_slots + 1;
-            uint2* ld = reinterpret_cast<uint2*>(nb + desc_off);
-            if (t <= hn.w) lc[t] = n_c;
-            if (t < hn.w) lz[t] = n_z;
-            const int nq = (hn2.y + 3) >> 2;
-            if (t < nq) ld[t] = n_d0;
-            if (t + SBLK < nq) ld[t + SBLK] = n_d1;
-        }
         __syncthreads();  // every wave is done with the tet records of this patch
         h = hn; h2 = hn2; hn = hnn; hn2 = hnn2;
         p = pn; pn = pnn;

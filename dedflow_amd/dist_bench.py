@@ -11,13 +11,41 @@ import time
 import numpy as np
 
 
-def setup_rank(mesh, rank, world, device, dist, its, staged):
-    """Partition, build the local problem on this rank's GPU and wire the communicator."""
+def distribute_problem(M, jitter, rank, world, dist):
+    """The mesh is generated and partitioned ONCE, on rank 0, and every rank is shipped its own piece: the local mesh (local
+    numbering, halo layer included), its maps and the localized state vectors.  No other rank ever holds the global mesh
+    (8 ranks each building the 10M-tet mesh and partitioning it cost 8x the host memory and time of one).  The pieces
+    travel as pickled objects over a CPU (gloo) group, so nothing of the setup touches RCCL.  DFL_DIST_SETUP=replicated:
+    every rank builds and partitions the global mesh itself (the round-1 behaviour), for A/B.
+    Returns (LocalMesh, wg_local, dwg_local, num_node_global, num_tet_global)."""
+    from . import dist as D
+    from .meshgen import kuhn_cube, synthetic_fields
+
+    def pieces(ranks):
+        mesh = kuhn_cube(M, jitter=jitter)
+        wg, dwg = synthetic_fields(mesh)
+        epart = D.partition_rcb(mesh, world)
+        owner = D.node_owner(mesh, epart, world)
+        out = []
+        for r in ranks:
+            lm = D.build_local(mesh, epart, owner, r, world)
+            out.append((lm, D.localize_vector(wg, lm, mesh.num_node), D.localize_vector(dwg, lm, mesh.num_node),
+                        mesh.num_node, mesh.num_tet))
+        return out
+
+    if world == 1 or os.environ.get("DFL_DIST_SETUP") == "replicated":
+        return pieces([rank])[0]
+    cpu = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+    objs = pieces(range(world)) if rank == 0 else None
+    mine = [None]
+    dist.scatter_object_list(mine, objs, src=0, group=cpu)
+    return mine[0]
+
+
+def setup_rank(lm, rank, world, device, dist, its, staged):
+    """Build the local problem on this rank's GPU and wire the communicator."""
     from . import api
     from . import dist as D
-    epart = D.partition_rcb(mesh, world)
-    owner = D.node_owner(mesh, epart, world)
-    lm = D.build_local(mesh, epart, owner, rank, world)
     # device buffers stay in the C layer's own pool (host/runtime.c); the torch.distributed fallback views them by pointer
     alloc = D.TorchDeviceAllocator(device) if os.environ.get("DFL_TORCH_ALLOCATOR") == "1" else D.RawPointerViews(device)
     P = api.Problem(lm.mesh, maxit=its, atol=0.0, rtol=0.0, quiet=True)
@@ -76,17 +104,15 @@ def run(args, rank, world, local_rank):
     staged = backend != "nccl"
 
     t_setup = time.perf_counter()
-    mesh = kuhn_cube(args.M, jitter=args.jitter)
-    wg, dwg = synthetic_fields(mesh)
     its = args.gmres_its
-    lm, alloc, P, plan, comm = setup_rank(mesh, rank, world, device, dist, its, staged)
-    Ng, Tg = mesh.num_node, mesh.num_tet
+    lm, wg_l, dwg_l, Ng, Tg = distribute_problem(args.M, args.jitter, rank, world, dist)
+    lm, alloc, P, plan, comm = setup_rank(lm, rank, world, device, dist, its, staged)
     n, no = P.N, lm.n_owned
-    wg_t, wg_p = device_vector(alloc, torch, device, 6 * n, D.localize_vector(wg, lm, Ng))
-    dwg_t, dwg_p = device_vector(alloc, torch, device, 6 * n, D.localize_vector(dwg, lm, Ng))
+    wg_t, wg_p = device_vector(alloc, torch, device, 6 * n, wg_l)
+    dwg_t, dwg_p = device_vector(alloc, torch, device, 6 * n, dwg_l)
     F_t, F_p = device_vector(alloc, torch, device, 6 * n)
     x_t, x_p = device_vector(alloc, torch, device, 6 * n)
-    del mesh, wg, dwg
+    del wg_l, dwg_l
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
     L = api.lib()
@@ -151,7 +177,8 @@ def run(args, rank, world, local_rank):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Kuhn cube M={args.M}: {Tg} tets, {Ng} nodes; step = AssembleSystem(F) + AssembleSystem(J) + "
                                    f"Jacobi-PC GMRES x{its} iterations; RCB element partition over {world} ranks, "
-                                   f"one halo layer assembled redundantly, halo exchange + all-reduce on {backend}",
+                                   f"one halo layer assembled redundantly, halo exchange + all-reduce on {backend}; mesh generated and "
+                                   f"partitioned once on rank 0, local pieces scattered",
                        "gmres_its": its, "parallelism": f"dd{world}"},
             "per_rank": {"local_tets": [r[0] for r in per_rank], "owned_nodes": [r[1] for r in per_rank],
                          "halo_send_bytes": [r[2] for r in per_rank], "colors": [r[3] for r in per_rank]},

@@ -40,6 +40,13 @@ def run_cpu(rank, world, M, its):
     owner = D.node_owner(mesh, epart, world)
     lm = D.build_local(mesh, epart, owner, rank, world)
     n, no, Ng = lm.l2g_node.size, lm.n_owned, mesh.num_node
+    # bench.py's setup (mesh generated and partitioned once on rank 0, pieces scattered) hands this rank the same piece
+    from dedflow_amd import dist_bench
+    lm_s, wg_s, dwg_s, Ng_s, Tg_s = dist_bench.distribute_problem(M, 0.2, rank, world, dist)
+    assert (Ng_s, Tg_s) == (mesh.num_node, mesh.num_tet) and lm_s.n_owned == no and lm_s.n_interior == lm.n_interior
+    assert np.array_equal(lm_s.l2g_node, lm.l2g_node) and np.array_equal(lm_s.mesh.ien, lm.mesh.ien)
+    assert np.array_equal(lm_s.mesh.xg, lm.mesh.xg) and np.array_equal(lm_s.ghost_owner, lm.ghost_owner)
+    assert np.array_equal(wg_s, D.localize_vector(wg, lm, Ng)) and np.array_equal(dwg_s, D.localize_vector(dwg, lm, Ng))
     # ownership is a partition of the nodes
     cnt = torch.tensor([float(no)], dtype=torch.float64)
     dist.all_reduce(cnt)
@@ -138,7 +145,15 @@ def run_gpu(rank, world, M, its):
     Sg, wg, dwg, Fg, valsg, xg_, histg, r0g = global_reference(mesh, its)
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    lm, alloc, P, plan, comm = dist_bench.setup_rank(mesh, rank, world, device, dist, its, True)
+    # the bench's own setup path: mesh generated + partitioned once on rank 0, pieces scattered over a CPU group
+    lm, wg_l, dwg_l, Ng_s, Tg_s = dist_bench.distribute_problem(M, 0.2, rank, world, dist)
+    assert (Ng_s, Tg_s) == (mesh.num_node, mesh.num_tet)
+    epart = D.partition_rcb(mesh, world)
+    lm_ref = D.build_local(mesh, epart, D.node_owner(mesh, epart, world), rank, world)   # what a replicated build gives
+    assert np.array_equal(lm.l2g_node, lm_ref.l2g_node) and np.array_equal(lm.mesh.ien, lm_ref.mesh.ien)
+    assert lm.n_owned == lm_ref.n_owned and lm.n_interior == lm_ref.n_interior
+    assert np.array_equal(wg_l, D.localize_vector(wg, lm_ref, mesh.num_node))
+    lm, alloc, P, plan, comm = dist_bench.setup_rank(lm, rank, world, device, dist, its, True)
     fused = os.environ.get("DFL_FUSED_NORM") == "1"
     if fused:  # one all-reduce per Arnoldi step (norm from w.w - sum h^2)
         api.lib().KrylovSetFusedNorm(P.ksp, 1)
@@ -198,7 +213,8 @@ def run_gpu_rccl(rank, world, M, its):
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     os.environ["DFL_COMM"] = "rccl"
-    lm, alloc, P, plan, comm = dist_bench.setup_rank(mesh, rank, world, device, dist, its, False)
+    lm, _, _, _, _ = dist_bench.distribute_problem(M, 0.2, rank, world, dist)
+    lm, alloc, P, plan, comm = dist_bench.setup_rank(lm, rank, world, device, dist, its, False)
     assert type(comm).__name__ == "RcclSolverComm", type(comm).__name__
     Ng, n, no = mesh.num_node, P.N, lm.n_owned
     wg_t, wg_p = dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(wg, lm, Ng))
@@ -239,7 +255,8 @@ def run_gpu_step(rank, world, M, its):
     it_o, rn_o, ri_o, wgold_o, dwgold_o, _ = time_step(Sg, wgold, dwgold, dwg, maxit=2)
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    lm, alloc, P, plan, comm = dist_bench.setup_rank(mesh, rank, world, device, dist, 120, True)
+    lm, _, _, _, _ = dist_bench.distribute_problem(M, 0.2, rank, world, dist)
+    lm, alloc, P, plan, comm = dist_bench.setup_rank(lm, rank, world, device, dist, 120, True)
     from dedflow_amd import api
     api.lib().KrylovDestroy(P.ksp)  # reference solver settings for the driver: GMRES(120), atol 1e-12, rtol 1e-4
     P.ksp = api.lib().KrylovCreateGMRES(120, 1e-12, 1e-4, None)
