@@ -230,6 +230,7 @@ void DflAssembleSystemPrepacked(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* 
     MeshExt* x = (MeshExt*)mesh->ext;
     x->nodep_current = prepacked && x->nodep != NULL;
     hipStream_t s = DflStream();
+    DflRangePush(F && J ? "AssembleSystem(F,J)" : F ? "AssembleSystem(F)" : "AssembleSystem(J)");
     if (F) HIPGUARD(hipMemsetAsync(F, 0, (size_t)num_node * sizeof(f64) * BS, s));
     /* schedule 3 writes every row of J exactly once: the zero pass folds into that write */
     const b32 overwrite = J && x->cfg.sched_mode >= 3 && Mesh3DNumTet(mesh) && MatrixFSBlockValues(J);
@@ -244,4 +245,5 @@ void DflAssembleSystemPrepacked(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* 
         if (F) DirichletApplyVec(bcs[ibc], F);
         if (J) DirichletApplyMat(bcs[ibc], J);
     }
+    DflRangePop();
 }

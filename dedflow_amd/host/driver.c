@@ -129,10 +129,12 @@ index_type DflTimeStep(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* 
     hipStream_t s = DflStream();
     const f64 fac_pred = (kGAMMA - 1.0) / kGAMMA;
     const f64 fac_corr[] = {kDT * (1.0 - kGAMMA), kDT * kGAMMA};
+    DflRangePush("DflTimeStep");
     dfl_alpha_predict(N, fac_pred, dwg, s);
     index_type it = SolveFlowSystem(mesh, wgold, dwgold, dwg, J, F, dx, ksp, bcs, nbc, newton_maxit, rnorm_out, rnorm_init_out);
     if (pctx)
         for (index_type k = 0; k < dem_substeps; ++k) ParticleContextUpdate(pctx); /* coupled step: contact sweep (config 4) */
     dfl_alpha_correct(N, fac_corr[0], fac_corr[1], wgold, dwgold, dwg, s);
+    DflRangePop();
     return it;
 }

@@ -139,4 +139,8 @@ index_type SolveFlowSystem(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matr
                            Dirichlet** bcs, index_type nbc, index_type maxit, f64* rnorm_out, f64* rnorm_init_out);
 void DflKrylovSolvePrepared(Krylov* ksp, Matrix* A, f64* x, f64* b); /* KrylovSolve without PC (re)build and PCSetup */
 
+/* named ranges for rocprofv3 --marker-trace (DFL_ROCTX=1); no-ops otherwise */
+void DflRangePush(const char* name);
+void DflRangePop(void);
+
 #endif

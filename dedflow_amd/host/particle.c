@@ -83,6 +83,7 @@ void ParticleContextComputeForces(ParticleContext* ctx) {
     const index_type P = ctx->num_particle;
     const f64 R = ParticleRadius(ctx);
     hipStream_t s = DflStream();
+    DflRangePush("ParticleContextComputeForces");
     index_type ncell = (index_type)floor(1.0 / (2.0 * R));
     if (ncell < 1) ncell = 1;
     if (ncell > 256) ncell = 256; /* 2^24 cells at most (the dense cell arrays); larger cells stay valid: edge >= 2R */
@@ -112,6 +113,7 @@ void ParticleContextComputeForces(ParticleContext* ctx) {
     int slot = DflProfileBegin(DFL_TAG_SMALL + 1);
     dfl_dem_forces(P, x->sorted, R, ParticleMass(ctx), x->kn, x->gamma_n, cell, ncell, x->order, x->cell_start, acc, s);
     DflProfileEnd(slot);
+    DflRangePop();
 }
 
 void ParticleContextUpdate(ParticleContext* ctx) {

@@ -2,6 +2,7 @@
  * Mirrors src/common.c:21-51 (Init/Finalize/GlobalContextGet) and src/alloc.c:8-50
  * (host malloc / device malloc + zero fill).  There are no vendor-library handles
  * on this path; the "handle" slots hand out the library stream. */
+#include <dlfcn.h>
 #include <string.h>
 #include "dedflow.h"
 #include "dedflow_kernels.h"
@@ -342,4 +343,35 @@ int DflProfileCollect(int tag, double* total_ms, double* min_ms) {
     if (total_ms) *total_ms = tot;
     if (min_ms) *min_ms = count ? mn : 0.0;
     return count;
+}
+
+/* ---- optional ROCTX ranges (tracing).  DFL_ROCTX=1 binds roctxRangePushA / roctxRangePop from
+ * librocprofiler-sdk-roctx.so (or libroctx64.so) at the first call; `rocprofv3 --kernel-trace --marker-trace` then shows AssembleSystem(F) / AssembleSystem(J) /
+ * KrylovSolve / DEM sweep / DflTimeStep as named ranges around their kernels.  Off (two loads of a static) otherwise. */
+static int g_roctx_state = 0; /* 0 = not looked at, 1 = bound, -1 = off */
+static int (*g_roctx_push)(const char*) = NULL;
+static int (*g_roctx_pop)(void) = NULL;
+static void roctx_bind(void) {
+    g_roctx_state = -1;
+    const char* e = getenv("DFL_ROCTX");
+    if (!e || !atoi(e)) return;
+    /* rocprofv3 (rocprofiler-sdk) listens to its own ROCTx library; the roctracer-era libroctx64 is the fallback */
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+        fprintf(stderr, "DFL_ROCTX: %s\n", dlerror());
+        return;
+    }
+    *(void**)(&g_roctx_push) = dlsym(h, "roctxRangePushA");
+    *(void**)(&g_roctx_pop) = dlsym(h, "roctxRangePop");
+    if (g_roctx_push && g_roctx_pop) g_roctx_state = 1;
+}
+void DflRangePush(const char* name) {
+    if (g_roctx_state == 0) roctx_bind();
+    if (g_roctx_state == 1) g_roctx_push(name);
+}
+void DflRangePop(void) {
+    if (g_roctx_state == 1) g_roctx_pop();
 }

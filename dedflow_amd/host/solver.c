@@ -749,8 +749,10 @@ void KrylovSolve(Krylov* ksp, Matrix* A, f64* x, f64* b) {
         }
         ksp->pc = pc;
     }
+    DflRangePush("KrylovSolve");
     PCSetup(pc);
     DflKrylovSolvePrepared(ksp, A, x, b);
+    DflRangePop();
 }
 
 /* the solve alone: ksp->pc exists and has been set up for the current values of A (inner solvers of PC_TWOLEVEL, whose
