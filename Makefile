@@ -39,7 +39,19 @@ $(LIB): $(KOBJ) $(HOBJ)
 oracle:
 	$(MAKE) -C oracle
 
-clean:
-	rm -f $(KOBJ) $(HOBJ) $(LIB)
+# CPU sanitizer build: the C host layer under AddressSanitizer + UBSan, linked with the same device objects (GPU ASan is
+# not available on this pool; sanitizers run on the CPU-only tests: tools/run_cpu_sanitized.sh)
+SANLIB  = dedflow_amd/libdedflow_asan.so
+SANOBJ  = $(HSRC:.c=.san.o)
+dedflow_amd/host/%.san.o: dedflow_amd/host/%.c include/dedflow.h include/dedflow_kernels.h dedflow_amd/host/host_private.h
+	$(CC) $(CFLAGS) -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -c $< -o $@
+$(SANLIB): $(KOBJ) $(SANOBJ)
+	$(HIPCC) -shared -fPIC -fopenmp --offload-arch=$(ARCH) -fsanitize=address,undefined -o $@ $^ || \
+	$(CC) -shared -fPIC -fopenmp -fsanitize=address,undefined -o $@ $^ -L$(ROCM)/lib -lamdhip64 -lstdc++ -Wl,-rpath,$(ROCM)/lib
+asan: $(SANLIB)
+	$(MAKE) -C oracle asan
 
-.PHONY: all oracle clean
+clean:
+	rm -f $(KOBJ) $(HOBJ) $(LIB) $(SANOBJ) $(SANLIB)
+
+.PHONY: all oracle clean asan

@@ -27,7 +27,8 @@ class MissingExtension(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libdedflow.so")
+    # DFL_LIB: an alternative build of the same library (`make asan`: host layer under AddressSanitizer / UBSan, CPU runs only)
+    return os.environ.get("DFL_LIB") or os.path.join(_HERE, "libdedflow.so")
 
 
 def lib():

@@ -30,7 +30,7 @@ def build() -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.environ.get("DFL_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # DFL_ORACLE_LIB: the sanitizer build
         if not os.path.exists(path):
             build()
         _LIB = C.CDLL(path)
