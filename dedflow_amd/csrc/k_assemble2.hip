@@ -184,7 +184,8 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, 
             const bool hi2 = (j >> 1) != 0, hi1 = (j & 1) != 0;
             for (int sq = t >> 2; sq < ns; sq += SBLK / 4) {
                 const int cb0 = s_coff[sq], cb1 = s_coff[sq + 1];
-                const long long nz = s_nz[sq];
+                const int nzr = s_nz[sq];  // bit 30: first quad of a split slot, bit 31: one of its other three quads
+                const long long nz = nzr & 0x3fffffff;
                 double acc[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.0;
@@ -227,6 +228,15 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, 
                 e0.y = (hi1 ? r8[3] : r8[1]) + dpp_quad<0xB1>(hi1 ? r8[1] : r8[3]);
                 e1.x = (hi1 ? r8[6] : r8[4]) + dpp_quad<0xB1>(hi1 ? r8[4] : r8[6]);
                 e1.y = (hi1 ? r8[7] : r8[5]) + dpp_quad<0xB1>(hi1 ? r8[5] : r8[7]);
+                if (nzr & 0xC0000000) {
+                    // split slot (host/slotpatch.c): its four parts sit in the four quads of this 16-lane DPP row; lane j of
+                    // the first quad collects lane j of the others: (q0 + q1) + (q2 + q3), two row shifts
+                    e0.x += dpp_quad<0x104>(e0.x); e0.y += dpp_quad<0x104>(e0.y);
+                    e1.x += dpp_quad<0x104>(e1.x); e1.y += dpp_quad<0x104>(e1.y);
+                    e0.x += dpp_quad<0x108>(e0.x); e0.y += dpp_quad<0x108>(e0.y);
+                    e1.x += dpp_quad<0x108>(e1.x); e1.y += dpp_quad<0x108>(e1.y);
+                    if (nzr < 0) continue;  // only the first quad stores
+                }
                 if (PROBE && (dbg & 8)) {
                     if (e0.x == 1.2345e300) val[nz] = e0.x + e0.y + e1.x + e1.y;
                     continue;

@@ -143,4 +143,6 @@ void DflKrylovSolvePrepared(Krylov* ksp, Matrix* A, f64* x, f64* b); /* KrylovSo
 void DflRangePush(const char* name);
 void DflRangePop(void);
 
+int DflDevicePoolEnabled(void); /* the default DEVICE allocator carves large requests out of its pool */
+
 #endif

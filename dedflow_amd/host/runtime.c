@@ -168,6 +168,11 @@ static void* pool_take(PoolChunk* c, size_t bytes) {
     return NULL;
 }
 
+int DflDevicePoolEnabled(void) {
+    pool_configure();
+    return g_pool_state == 1;
+}
+
 static void* pool_alloc(size_t bytes) {
     pool_configure();
     if (g_pool_state != 1 || bytes < POOL_MIN_REQUEST) return NULL;

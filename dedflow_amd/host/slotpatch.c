@@ -27,6 +27,10 @@
 #include "dedflow_kernels.h"
 #include "host_private.h"
 
+#define SPLIT_MIN 12              /* contributions from which a (diagonal) slot is cut into four quads */
+#define SLOT_LEADER 0x40000000    /* slot_nz flag: first quad of a split slot (sums the four quads, stores the line) */
+#define SLOT_FOLLOWER 0x80000000u /* slot_nz flag: quads 2-4 of a split slot (no store) */
+
 typedef struct { index_type lo, hi; } Range;
 typedef struct {
     const f64* c;          /* node coordinates */
@@ -99,7 +103,8 @@ static void split(Ctx* x, index_type lo, index_type hi) {
         for (index_type i = lo; i < hi; ++i) slots += x->rp[x->idx[i] + 1] - x->rp[x->idx[i]];
         int64_t items = 0; /* (tet, owned node) pairs: 4 contributions each, at most 2048 per patch (8 per lane) */
         for (index_type i = lo; i < hi; ++i) items += x->vp[x->idx[i] + 1] - x->vp[x->idx[i]];
-        if (n <= 1 || (slots <= x->cap && items <= 512 && count_tets(x, lo, hi) <= x->tcap)) { emit(x, lo, hi); return; }
+        /* + 3 positions per node: a diagonal slot (>= SPLIT_MIN contributions) is walked by four quads */
+        if (n <= 1 || (slots + 3 * (int64_t)n <= x->cap && items <= 512 && count_tets(x, lo, hi) <= x->tcap)) { emit(x, lo, hi); return; }
     }
     f64 bl[3] = {1e300, 1e300, 1e300}, bh[3] = {-1e300, -1e300, -1e300};
     for (index_type i = lo; i < hi; ++i)
@@ -111,6 +116,8 @@ static void split(Ctx* x, index_type lo, index_type hi) {
     int ax = 0;
     if (bh[1] - bl[1] > bh[ax] - bl[ax]) ax = 1;
     if (bh[2] - bl[2] > bh[ax] - bl[ax]) ax = 2;
+    /* plain halving (cutting at multiples of the leaf size was measured: leaves of 9-12 nodes break the tet cap and are
+       halved again into more, smaller patches -- 3.0-3.3 ms against 2.84 ms) */
     const index_type half = n / 2;
     select_kth(x->c, ax, x->idx + lo, n, half);
     if (n > 4096) {
@@ -201,8 +208,12 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     int64_t tot_t = 0, tot_s = 0;
     index_type maxt = 0, maxs = 0;
     for (index_type p = 0; p < P; ++p) {
-        int64_t ns = 0;
-        for (index_type i = x.out[p].lo; i < x.out[p].hi; ++i) ns += rp[idx[i] + 1] - rp[idx[i]];
+        int64_t ns = 0; /* slot POSITIONS: one per nodal nonzero + 3 more for every split diagonal slot */
+        for (index_type i = x.out[p].lo; i < x.out[p].hi; ++i) {
+            ns += rp[idx[i] + 1] - rp[idx[i]];
+            if (vp[idx[i] + 1] - vp[idx[i]] >= SPLIT_MIN) ns += 3;
+        }
+        ASSERT(ns <= 255 || x.out[p].hi - x.out[p].lo == 1);
         ASSERT(nt_of[p] <= 4095 && "slot-patch descriptors hold 12-bit local tet ids");
         hdr[8 * p + 0] = (int32_t)tot_t;
         hdr[8 * p + 1] = nt_of[p];
@@ -214,14 +225,14 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
         if (nt_of[p] > maxt) maxt = nt_of[p];
         if (ns > maxs) maxs = (index_type)ns;
     }
-    ASSERT(tot_s == spy->nnz);
+    ASSERT(tot_s >= spy->nnz && tot_s < 2147483647LL);
     if (verbose)
         fprintf(stderr, "[slotpatch] %d patches (<= %d nodes / %d slots / %d tets): %.2f tets per patch-tet list entry per tet, max tets %d, "
                         "max slots %d, %.2f s\n", P, leaf, slot_cap, tet_cap, (double)tot_t / (double)(T > 0 ? T : 1), maxt, maxs, omp_get_wtime() - t0);
 
     index_type* ptet_ien = (index_type*)malloc(sizeof(index_type) * 4 * (size_t)(tot_t > 0 ? tot_t : 1));
-    index_type* slot_nz = (index_type*)malloc(sizeof(index_type) * (size_t)spy->nnz);
-    index_type* coff = (index_type*)malloc(sizeof(index_type) * ((size_t)spy->nnz + 1));
+    index_type* slot_nz = (index_type*)malloc(sizeof(index_type) * (size_t)tot_s);
+    index_type* coff = (index_type*)malloc(sizeof(index_type) * ((size_t)tot_s + 1));
     uint16_t* desc = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)T * 16);
     /* contribution counts per patch first (prefix over patches), then the fill */
     int64_t* cbase = (int64_t*)malloc(sizeof(int64_t) * ((size_t)P + 1));
@@ -240,7 +251,9 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     for (index_type p = 0; p < P; ++p) {
         const index_type lo = x.out[p].lo, nn = x.out[p].hi - lo;
         const index_type* nodes = idx + lo;
-        const index_type ntp = nt_of[p], ns = hdr[8 * p + 3], s0 = hdr[8 * p + 2];
+        const index_type ntp = nt_of[p], s0 = hdr[8 * p + 2];
+        index_type ns = 0; /* real slots (nodal nonzeros of the patch rows); hdr[8 p + 3] counts positions */
+        for (index_type k = 0; k < nn; ++k) ns += rp[nodes[k] + 1] - rp[nodes[k]];
         const index_type* tl = tets_of[p];
         for (index_type k = 0; k < ntp; ++k) memcpy(ptet_ien + ((size_t)hdr[8 * p] + k) * 4, ien + (size_t)tl[k] * 4, 4 * sizeof(index_type));
         index_type* rowbase = (index_type*)malloc(sizeof(index_type) * (size_t)nn);
@@ -277,45 +290,81 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
                 cnt[s]++;
             }
         }
-        /* slots sorted by count (descending, stable), dealt to the four waves in snake order (chunks of 16 quads) */
+        /* Positions.  A diagonal slot (>= SPLIT_MIN contributions; 24 in the interior of a Kuhn mesh against 4-6 for an
+           edge slot) is cut into four consecutive parts, each walked by its own quad -- four adjacent quads = one 16-lane
+           DPP row, summed by two row shifts in the kernel -- so that every quad of a wave pass has 1-2 trips instead of
+           the whole pass waiting 6 trips for its diagonal slots.  Ranks: the split slots first (4 ranks each, descending
+           count), then the others by descending count; ranks are dealt to the four waves in snake order in chunks of 16
+           quads (a multiple of 4: the groups stay aligned). */
+        const index_type np = hdr[8 * p + 3];
+        index_type* first_rank = (index_type*)malloc(sizeof(index_type) * (size_t)(ns > 0 ? ns : 1));
+        unsigned char* is_split = (unsigned char*)calloc((size_t)(ns > 0 ? ns : 1), 1);
+        {
+            index_type sidx = 0;
+            for (index_type k = 0; k < nn; ++k) {
+                const index_type dz = find_nz(rp, ci, nodes[k], nodes[k]) - rp[nodes[k]];
+                if (vp[nodes[k] + 1] - vp[nodes[k]] >= SPLIT_MIN) is_split[sidx + dz] = 1;
+                sidx += rp[nodes[k] + 1] - rp[nodes[k]];
+            }
+        }
         index_type maxc = 0;
         for (index_type s = 0; s < ns; ++s) if (cnt[s] > maxc) maxc = cnt[s];
-        index_type* bucket = (index_type*)calloc((size_t)maxc + 2, sizeof(index_type));
-        for (index_type s = 0; s < ns; ++s) bucket[maxc - cnt[s] + 1]++;
-        for (index_type c = 0; c <= maxc; ++c) bucket[c + 1] += bucket[c];
-        index_type* pos_of = (index_type*)malloc(sizeof(index_type) * (size_t)(ns > 0 ? ns : 1));
-        const index_type full = (ns / 64) * 64;
+        index_type* bucket = (index_type*)calloc(2 * ((size_t)maxc + 2), sizeof(index_type));
+        index_type* bsplit = bucket, *bsingle = bucket + maxc + 2;
+        index_type nsplit = 0;
         for (index_type s = 0; s < ns; ++s) {
-            const index_type r = bucket[maxc - cnt[s]]++;
-            index_type pos = r;
-            if (r < full) {
-                const index_type chunk = r >> 4, i = r & 15, k = chunk >> 2, w = chunk & 3;
-                pos = k * 64 + ((k & 1) ? 3 - w : w) * 16 + i;
-            }
-            pos_of[s] = pos;
+            if (is_split[s]) { bsplit[maxc - cnt[s] + 1]++; nsplit++; }
+            else bsingle[maxc - cnt[s] + 1]++;
         }
-        /* offsets in position order */
-        index_type* cpos = (index_type*)malloc(sizeof(index_type) * ((size_t)ns + 1));
-        for (index_type s = 0; s < ns; ++s) cpos[pos_of[s] + 1] = cnt[s];
-        cpos[0] = 0;
-        for (index_type s = 0; s < ns; ++s) cpos[s + 1] += cpos[s];
-        for (index_type s = 0; s < ns; ++s) coff[s0 + s] = (index_type)(cbase[p] + cpos[s]);
+        for (index_type c = 0; c <= maxc; ++c) { bsplit[c + 1] += bsplit[c]; bsingle[c + 1] += bsingle[c]; }
+        ASSERT(np == ns + 3 * nsplit);
+        for (index_type s = 0; s < ns; ++s)
+            first_rank[s] = is_split[s] ? 4 * bsplit[maxc - cnt[s]]++ : 4 * nsplit + bsingle[maxc - cnt[s]]++;
+        const index_type full = (np / 64) * 64;
+#define RANK_TO_POS(r) ((r) < full ? (((r) >> 6) * 64 + (((((r) >> 6) & 1) ? 3 - (((r) >> 4) & 3) : (((r) >> 4) & 3)) * 16) + ((r) & 15)) : (r))
+        /* contribution counts in position order, then offsets */
+        index_type* cpos = (index_type*)calloc((size_t)np + 1, sizeof(index_type));
+        for (index_type s = 0; s < ns; ++s) {
+            if (is_split[s])
+                for (index_type v = 0; v < 4; ++v)
+                    cpos[RANK_TO_POS(first_rank[s] + v) + 1] = (index_type)((int64_t)cnt[s] * (v + 1) / 4 - (int64_t)cnt[s] * v / 4);
+            else cpos[RANK_TO_POS(first_rank[s]) + 1] = cnt[s];
+        }
+        for (index_type q = 0; q < np; ++q) cpos[q + 1] += cpos[q];
+        for (index_type q = 0; q < np; ++q) coff[s0 + q] = (index_type)(cbase[p] + cpos[q]);
         {
             index_type sidx = 0;
             for (index_type k = 0; k < nn; ++k)
-                for (index_type z = rp[nodes[k]]; z < rp[nodes[k] + 1]; ++z) slot_nz[s0 + pos_of[sidx++]] = z;
+                for (index_type z = rp[nodes[k]]; z < rp[nodes[k] + 1]; ++z, ++sidx) {
+                    if (is_split[sidx]) {
+                        slot_nz[s0 + RANK_TO_POS(first_rank[sidx])] = z | SLOT_LEADER;
+                        for (index_type v = 1; v < 4; ++v) slot_nz[s0 + RANK_TO_POS(first_rank[sidx] + v)] = z | SLOT_FOLLOWER;
+                    } else slot_nz[s0 + RANK_TO_POS(first_rank[sidx])] = z;
+                }
         }
+        index_type* seen = (index_type*)calloc((size_t)(ns > 0 ? ns : 1), sizeof(index_type));
         for (index_type i = 0; i < m; ++i) {
             const index_type a = (index_type)((it[i] >> 16) & 3);
             for (int b = 0; b < 4; ++b) {
                 const index_type s = islot[4 * i + b];
-                desc[cbase[p] + cpos[pos_of[s]]++] = (uint16_t)((ilt[i] << 4) | (a << 2) | b);
+                index_type r = first_rank[s];
+                if (is_split[s]) { /* part v holds contributions [c v / 4, c (v + 1) / 4) of the slot's ascending list */
+                    const index_type k = seen[s]++;
+                    index_type v = (index_type)(((int64_t)k * 4) / cnt[s]);
+                    while ((int64_t)cnt[s] * (v + 1) / 4 <= k) ++v;
+                    while ((int64_t)cnt[s] * v / 4 > k) --v;
+                    r += v;
+                }
+                desc[cbase[p] + cpos[RANK_TO_POS(r)]++] = (uint16_t)((ilt[i] << 4) | (a << 2) | b);
             }
         }
+#undef RANK_TO_POS
+        free(seen); free(is_split); free(first_rank);
+        index_type* pos_of = NULL;
         free(cpos); free(pos_of); free(bucket); free(ilt); free(islot); free(it); free(cnt); free(rowbase);
         free(tets_of[p]);
     }
-    coff[spy->nnz] = (index_type)cbase[P];
+    coff[tot_s] = (index_type)cbase[P];
     ps->num_patch = P;
     ps->max_tets = maxt;
     ps->max_slots = maxs;
@@ -323,13 +372,13 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     ps->total_tets = tot_t;
     ps->d_hdr = (int32_t*)CdamMallocDevice((ptrdiff_t)P * 8 * (ptrdiff_t)sizeof(int32_t) + 32);
     ps->d_ptet_ien = (index_type*)CdamMallocDevice((ptrdiff_t)(tot_t > 0 ? tot_t : 1) * 4 * SIZE_OF(index_type));
-    ps->d_slot_nz = (index_type*)CdamMallocDevice((ptrdiff_t)spy->nnz * SIZE_OF(index_type));
-    ps->d_coff = (index_type*)CdamMallocDevice(((ptrdiff_t)spy->nnz + 1) * SIZE_OF(index_type));
+    ps->d_slot_nz = (index_type*)CdamMallocDevice((ptrdiff_t)tot_s * SIZE_OF(index_type));
+    ps->d_coff = (index_type*)CdamMallocDevice(((ptrdiff_t)tot_s + 1) * SIZE_OF(index_type));
     ps->d_desc = (uint16_t*)CdamMallocDevice((ptrdiff_t)T * 16 * (ptrdiff_t)sizeof(uint16_t));
     HIPGUARD(hipMemcpy(ps->d_hdr, hdr, sizeof(int32_t) * 8 * (size_t)P, H2D));
     HIPGUARD(hipMemcpy(ps->d_ptet_ien, ptet_ien, sizeof(index_type) * 4 * (size_t)tot_t, H2D));
-    HIPGUARD(hipMemcpy(ps->d_slot_nz, slot_nz, sizeof(index_type) * (size_t)spy->nnz, H2D));
-    HIPGUARD(hipMemcpy(ps->d_coff, coff, sizeof(index_type) * ((size_t)spy->nnz + 1), H2D));
+    HIPGUARD(hipMemcpy(ps->d_slot_nz, slot_nz, sizeof(index_type) * (size_t)tot_s, H2D));
+    HIPGUARD(hipMemcpy(ps->d_coff, coff, sizeof(index_type) * ((size_t)tot_s + 1), H2D));
     HIPGUARD(hipMemcpy(ps->d_desc, desc, sizeof(uint16_t) * (size_t)T * 16, H2D));
     if (verbose) fprintf(stderr, "[slotpatch] uploaded at %.2f s\n", omp_get_wtime() - t0);
     free(cbase); free(desc); free(coff); free(slot_nz); free(ptet_ien); free(hdr); free(nt_of); free(tets_of);

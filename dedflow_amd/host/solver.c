@@ -217,6 +217,7 @@ typedef struct KrylovExt {
     const Mesh3D* mesh; /* optional: node coordinates for preconditioners that aggregate nodes (PC_TWOLEVEL) */
     index_type agg_size; /* PC_TWOLEVEL: nodes per aggregate */
     b32 fused_norm; /* partitioned runs: ||w - Qh|| from w.w - sum h^2, one all-reduce per Arnoldi step (off by default) */
+    int q_pooled;   /* the basis Q came from the device pool (placement calibration may pick either kind) */
     int* d_flag;    /* device int raised by the fused-norm kernel on heavy cancellation */
     f64* hraw;      /* [ldh] raw CGS coefficients + w.w of the current column (fused update + PC + Givens kernel) */
     /* cached GMRES work space */
@@ -292,7 +293,7 @@ static void ws_vec_free_as(f64* p, int pooled) {
 }
 
 static void ws_free(KrylovExt* x) {
-    ws_vec_free_as(x->Q, x->ws_pooled); ws_vec_free_as(x->Z, x->ws_pooled); CdamFreeDevice(x->H, 0); ws_vec_free_as(x->tmp, x->ws_pooled); CdamFreeDevice(x->gv, 0);
+    ws_vec_free_as(x->Q, x->q_pooled); ws_vec_free_as(x->Z, x->ws_pooled); CdamFreeDevice(x->H, 0); ws_vec_free_as(x->tmp, x->ws_pooled); CdamFreeDevice(x->gv, 0);
     CdamFreeDevice(x->beta, 0); CdamFreeDevice(x->res_hist, 0); CdamFreeDevice(x->nrm, 0); CdamFreeDevice(x->work, 0);
     CdamFreeDevice(x->d_flag, 0);
     CdamFreeDevice(x->hraw, 0);
@@ -308,6 +309,7 @@ static void ws_ensure(KrylovExt* x, index_type n, index_type maxit, index_type l
     ws_free(x);
     x->ws_pooled = ws_in_pool();
     x->Q = ws_vec_malloc((ptrdiff_t)n * (maxit + 1));
+    x->q_pooled = x->ws_pooled;
     x->H = (f64*)CdamMallocDevice((ptrdiff_t)ldh * maxit * SIZE_OF(f64));
     x->tmp = ws_vec_malloc((ptrdiff_t)n * 2);
     x->gv = (f64*)CdamMallocDevice(2 * (ptrdiff_t)maxit * SIZE_OF(f64));
@@ -386,14 +388,20 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     if (ncand < 2 || ws_in_pool() || !MatrixFSBlockValues(A) || ex->has_comm || m < 8 || na < (1 << 20)) return first;
     hipStream_t s = DflStream();
     f64* cand[8];
+    int pooled[8];
     float best_ms[8];
     int n = 1;
     cand[0] = first;
+    pooled[0] = ex->q_pooled;
     for (; n < ncand; ++n) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (size_t)count * sizeof(f64) + ((size_t)4 << 30)) break;
         void* p = NULL;
-        if (hipMalloc(&p, (size_t)count * sizeof(f64)) != hipSuccess) { (void)hipGetLastError(); break; }
+        /* the second candidate comes from the device pool: which of the two kinds of address range is the slow one
+           differs from process to process (the value array sits in the pool; measured both ways round) */
+        pooled[n] = (n == 1 && !ex->q_pooled && DflDevicePoolEnabled());
+        if (pooled[n]) p = CdamMallocDevice(count * SIZE_OF(f64));
+        else if (hipMalloc(&p, (size_t)count * sizeof(f64)) != hipSuccess) { (void)hipGetLastError(); break; }
         HIPGUARD(hipMemsetAsync(p, 0, (size_t)count * sizeof(f64), s));
         cand[n] = (f64*)p;
     }
@@ -427,12 +435,13 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     HIPGUARD(hipEventDestroy(b));
     if (getenv("DFL_WS_VERBOSE")) {
         fprintf(stderr, "[krylov] basis placement: in-loop SpMV into %d candidates:", n);
-        for (int k = 0; k < n; ++k) fprintf(stderr, " %.4f%s", best_ms[k], k == best ? "*" : "");
+        for (int k = 0; k < n; ++k) fprintf(stderr, " %.4f%s%s", best_ms[k], pooled[k] ? "(pool)" : "", k == best ? "*" : "");
         fprintf(stderr, " ms\n");
     }
     HIPGUARD(hipStreamSynchronize(s));
     for (int k = 0; k < n; ++k)
-        if (k != best) HIPGUARD(hipFree(cand[k]));
+        if (k != best) ws_vec_free_as(cand[k], pooled[k]);
+    ex->q_pooled = pooled[best];
     return cand[best]; /* all-zero: only zero vectors went through the kernels above */
 }
 
