@@ -208,6 +208,7 @@ void PCDestroy(PC* pc) {
 typedef struct KrylovExt {
     KrylovStats stats;
     index_type check_interval;
+    b32 check_interval_set; /* KrylovSetCheckInterval was called: PC_TWOLEVEL leaves the interval alone */
     b32 verbose;
     DflComm comm;
     b32 has_comm;
@@ -246,7 +247,10 @@ static Krylov* krylov_init(index_type max_iter, f64 atol, f64 rtol, void* handle
 }
 
 const KrylovStats* KrylovGetStats(const Krylov* k) { return &kext(k)->stats; }
-void KrylovSetCheckInterval(Krylov* k, index_type n) { kext(k)->check_interval = n > 0 ? n : 20; }
+void KrylovSetCheckInterval(Krylov* k, index_type n) {
+    kext(k)->check_interval = n > 0 ? n : 20;
+    kext(k)->check_interval_set = TRUE;
+}
 void KrylovSetVerbose(Krylov* k, b32 v) { kext(k)->verbose = v; }
 void KrylovSetPCType(Krylov* k, PCType type) {
     if (kext(k)->pc_type != type) { /* rebuilt at the next KrylovSolve */
@@ -736,6 +740,10 @@ void KrylovSolve(Krylov* ksp, Matrix* A, f64* x, f64* b) {
     PC* pc = (PC*)ksp->pc;
     if (pc == NULL || pc->mat != A) {
         PCDestroy(pc);
+        /* convergence test every 20th iteration (krylov.c:281) -- every 4th under PC_TWOLEVEL, where an iteration costs two
+           fine-level matvecs, a DILU sweep and a coarse solve and the 8-byte read nothing -- unless the caller chose */
+        if (!kext(ksp)->check_interval_set)
+            kext(ksp)->check_interval = (kext(ksp)->pc_type == PC_TWOLEVEL && MatrixFSBlockValues(A) && kext(ksp)->mesh) ? 4 : 20;
         if (kext(ksp)->pc_type == PC_TWOLEVEL && MatrixFSBlockValues(A) && kext(ksp)->mesh) {
             pc = PCCreateTwoLevel(A, kext(ksp)->mesh, kext(ksp)->agg_size);
             kext(ksp)->flexible = TRUE; /* the coarse level is solved by an inner Krylov iteration: the PC varies */
