@@ -816,6 +816,7 @@ extern "C" {
 
 int g_patch_dbg = 0;
 void dfl_tune_asm(int v) { g_patch_dbg = v; }
+int dfl_tune_asm_flags(void) { return g_patch_dbg; }
 void dfl_elem_geometry(I T_, const I* ien_x, const T* xg, T* egeo, void* stream) {
     if (T_ <= 0) return;
     elem_geometry_kernel<<<ceil_div(T_, 256), 256, 0, S(stream)>>>(T_, ien_x, xg, egeo);

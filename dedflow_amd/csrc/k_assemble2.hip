@@ -343,25 +343,25 @@ __global__ __launch_bounds__(256) void tet_rhs_wave_kernel(I P, const I* __restr
 struct LaneLists {
     int c, nid;   // requested two patches ahead (the node ids feed the record gather of the next patch)
     unsigned ln;  // 4 local node ids of this lane's tet, one byte each; this and the rest: one patch ahead
-    uint2 adj2;
+    uint4 sub;    // two sub-lists of the ordered sum (4 result slots each, u16)
     unsigned st0, st1;
 };
 
 // every load unconditional (padded layout: all addresses valid) so that the compiler can count the loads in flight exactly
 template <int NODES, bool HEAD_ONLY>
 __device__ __forceinline__ LaneLists lane_load_lists(int pp, int lane, const I* __restrict__ cnt, const I* __restrict__ pnode,
-                                                     const unsigned char* __restrict__ lien, const unsigned short* __restrict__ adj,
-                                                     const unsigned short* __restrict__ adj_start) {
+                                                     const unsigned char* __restrict__ lien, const unsigned short* __restrict__ sub4,
+                                                     const unsigned short* __restrict__ sub_start) {
     static_assert(NODES == 64, "one node id per lane");
     LaneLists L;
     L.c = cnt[pp];
     L.nid = pnode[(long long)pp * NODES + lane];
     if (HEAD_ONLY) return L;
     L.ln = reinterpret_cast<const unsigned*>(lien)[(long long)pp * 64 + lane];
-    L.adj2 = reinterpret_cast<const uint2*>(adj + (long long)pp * 256)[lane];
-    const unsigned short* st = adj_start + (long long)pp * (NODES + 1);
+    L.sub = reinterpret_cast<const uint4*>(sub4 + (long long)pp * 512)[lane];
+    const unsigned short* st = sub_start + (long long)pp * (NODES + 1);
     L.st0 = st[lane];
-    L.st1 = st[NODES];  // the last entry, same address for every lane
+    L.st1 = st[NODES];  // the last entry (= number of sub-lists), same address for every lane
     return L;
 }
 
@@ -370,15 +370,17 @@ __device__ __forceinline__ LaneLists lane_load_lists(int pp, int lane, const I* 
 template <int NODES, int WPS, bool PROBE>  // WPS = waves per SIMD the registers are budgeted for (1: no spills; 2: 256 VGPRs)
 __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __restrict__ cnt, const I* __restrict__ pnode,
                                                              const unsigned char* __restrict__ lien,
-                                                             const unsigned short* __restrict__ adj,
-                                                             const unsigned short* __restrict__ adj_start,
+                                                             const unsigned short* __restrict__ sub4,
+                                                             const unsigned short* __restrict__ sub_start,
                                                              const T* __restrict__ nodep, T* __restrict__ partial, int dbg_in) {
     const int dbg = PROBE ? dbg_in : 0;
     constexpr int RS = NV + 1;                 // padded node record in LDS
     constexpr int NJ = (NODES * 7 + 63) / 64;  // 16-byte pieces of the node records per lane
-    constexpr int BUF = NODES * RS > 6 * 256 ? NODES * RS : 6 * 256;
+    constexpr int OS = 260;                    // stride of one component of the parked results; slot 256 holds 0.0
+    constexpr int BUF = NODES * RS > 6 * OS ? NODES * RS : 6 * OS;
     __shared__ __attribute__((aligned(16))) double s_buf[4][BUF];
-    __shared__ __attribute__((aligned(16))) unsigned short s_adj[4][256 + 8];  // + 8: the 4-entry reads may run past a list
+    __shared__ double s_subv[4][(128 + 4) * 6];  // sub-list sums, [sub-list][component]
+    __shared__ __attribute__((aligned(16))) unsigned short s_sub4[4][512];
     __shared__ unsigned short s_st[4][NODES + 2];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // w in an SGPR: patch ids,
                                                                                               // LDS bases scalar
@@ -412,16 +414,16 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
                 sb[G_LN(j) * RS + 2 * G_PART(j)] = rv[j].x;
                 sb[G_LN(j) * RS + 2 * G_PART(j) + 1] = rv[j].y;
             }
-        reinterpret_cast<uint2*>(s_adj[w])[lane] = L.adj2;
+        reinterpret_cast<uint4*>(s_sub4[w])[lane] = L.sub;
         s_st[w][lane] = (unsigned short)L.st0;
         if (lane == 0) s_st[w][NODES] = (unsigned short)L.st1;
     };
 
-    LaneLists L1 = lane_load_lists<NODES, false>(p, lane, cnt, pnode, lien, adj, adj_start);
+    LaneLists L1 = lane_load_lists<NODES, false>(p, lane, cnt, pnode, lien, sub4, sub_start);
     gather(L1.nid);
     int pn = p + wx;
     bool has_n = pn < pend;
-    LaneLists L2 = lane_load_lists<NODES, true>(min(pn, pend - 1), lane, cnt, pnode, lien, adj, adj_start);
+    LaneLists L2 = lane_load_lists<NODES, true>(min(pn, pend - 1), lane, cnt, pnode, lien, sub4, sub_start);
     stage(L1);
     // the head of the second patch's lists is complete before the loop is entered: inside the loop the same registers
     // are waited for with the stores of the previous patch still in flight, and the compiler merges the two states
@@ -584,21 +586,41 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
         const int pnn = pn + wx;
         const bool has_nn = pnn < pend;
         {
-            const LaneLists T2 = lane_load_lists<NODES, false>(min(pn, pend - 1), lane, cnt, pnode, lien, adj, adj_start);
-            L2.ln = T2.ln; L2.adj2 = T2.adj2; L2.st0 = T2.st0; L2.st1 = T2.st1;  // (c and nid are re-read: same values)
+            const LaneLists T2 = lane_load_lists<NODES, false>(min(pn, pend - 1), lane, cnt, pnode, lien, sub4, sub_start);
+            L2.ln = T2.ln; L2.sub = T2.sub; L2.st0 = T2.st0; L2.st1 = T2.st1;  // (c and nid are re-read: same values)
         }
-        const LaneLists L3 = lane_load_lists<NODES, true>(min(pnn, pend - 1), lane, cnt, pnode, lien, adj, adj_start);
+        const LaneLists L3 = lane_load_lists<NODES, true>(min(pnn, pend - 1), lane, cnt, pnode, lien, sub4, sub_start);
         WAVE_SYNC();  // every lane is done with the node records: the slice now takes the per-(tet, vertex) results
         if (lane < ne) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                double2* dst = reinterpret_cast<double2*>(sb + j * 256 + lane * 4);
+                double2* dst = reinterpret_cast<double2*>(sb + j * OS + lane * 4);
                 dst[0] = make_double2(out[j], out[6 + j]);
                 dst[1] = make_double2(out[12 + j], out[18 + j]);
             }
         }
+        if (lane < 6) sb[lane * OS + 256] = 0.0;  // the slot the padding of a sub-list points at
         WAVE_SYNC();
-        // ordered sum per patch node: contributions in ascending local tet order
+        // Ordered sum per patch node, two fixed-shape levels (host/patch.c): level 1 -- every (sub-list, component) pair sums
+        // its 4 result slots, the same work for every lane whatever the valence of the node (a per-node walk made the
+        // whole wave wait for its 24-tet nodes: 0.37 of the kernel's 1.1 ms); level 2 -- every (node, component) pair adds
+        // its 1-6 sub-list sums in order.  Fixed association ((a0+a1)+a2)+a3 per sub-list, then sub-lists in order.
+        {
+            const int ns6 = (int)s_st[w][NODES] * 6;  // entry NODES = number of sub-lists (entries >= nn repeat it)
+            const double* subv_end = nullptr;
+            (void)subv_end;
+            if (!(PROBE && (dbg & 256))) {
+#pragma unroll 2
+                for (int tk = lane; tk < ns6; tk += 64) {
+                    const int s6 = tk / 6, j = tk - 6 * s6;
+                    const uint2 id = reinterpret_cast<const uint2*>(s_sub4[w])[s6];
+                    const double* o = sb + j * OS;
+                    const double v0 = o[id.x & 0xffffu], v1 = o[id.x >> 16], v2 = o[id.y & 0xffffu], v3 = o[id.y >> 16];
+                    s_subv[w][tk] = ((v0 + v1) + v2) + v3;
+                }
+            }
+        }
+        WAVE_SYNC();
         // (all NODES * 6 entries of the padded partial block are written, the unused ones as zeros: a fixed number of
         // unconditional stores per lane, so that waiting for the loads above never waits for these stores)
 #pragma unroll
@@ -608,16 +630,14 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
             double sum = 0.0;
             if (PROBE && (dbg & 256)) sum = sb[k];
             else if (ln < nn) {
-                // four list entries per trip, all their LDS reads in flight together; the additions stay in list order
-                // (a walk of one entry per trip pays two dependent LDS latencies per entry: it dominated the kernel)
-                const int q1 = s_st[w][ln + 1];
-                for (int q = s_st[w][ln]; q < q1; q += 4) {
-                    const int i0 = s_adj[w][q], i1 = s_adj[w][q + 1] & 255, i2 = s_adj[w][q + 2] & 255, i3 = s_adj[w][q + 3] & 255;  // past the list: any valid slot
-                    const double v0 = sb[j * 256 + i0], v1 = sb[j * 256 + i1], v2 = sb[j * 256 + i2], v3 = sb[j * 256 + i3];
+                const int s1 = s_st[w][ln + 1];
+                for (int q = s_st[w][ln]; q < s1; q += 4) {  // 1-6 sub-lists per node: one trip, two for a 24-tet node
+                    const double v0 = s_subv[w][q * 6 + j], v1 = s_subv[w][(q + 1) * 6 + j], v2 = s_subv[w][(q + 2) * 6 + j],
+                                 v3 = s_subv[w][(q + 3) * 6 + j];
                     sum += v0;
-                    if (q + 1 < q1) sum += v1;
-                    if (q + 2 < q1) sum += v2;
-                    if (q + 3 < q1) sum += v3;
+                    if (q + 1 < s1) sum += v1;
+                    if (q + 2 < s1) sum += v2;
+                    if (q + 3 < s1) sum += v3;
                 }
             }
             if (!(PROBE && (dbg & 1024))) partial[n0 * 6 + k] = sum;
@@ -700,28 +720,7 @@ void dfl_assemble_tet_rhs_wave(I npatch, I pad_tets, I pad_nodes, const I* cnt, 
     const int grid = 8 * (per / 4);
     if (pad_tets == 32 && pad_nodes == 48)
         tet_rhs_wave_kernel<32, 48><<<grid, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial);
-    else if (pad_tets == 64 && pad_nodes == 64 && !(g_patch_dbg & 32)) {
-        // lane-per-tet kernel, persistent waves: 2 workgroups per CU (built for 2 waves per SIMD; measured 0.89 ms at 10M tets
-        // against 1.07 ms for the 1-wave build and 1.29 ms for the 4-lanes-per-tet wave kernel)
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            DFL_GUARD(hipGetDevice(&dev));
-            DFL_GUARD(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            if (cus < 8) cus = 8;
-        }
-        const int wps = (g_patch_dbg & 64) ? 1 : 2;  // developer A/B: bit 64 = the 1-wave-per-SIMD build (no spills, 512 registers)
-        int g = (wps * cus) / 8 * 8;
-        const int need = 8 * ((((npatch + 7) / 8) + 3) / 4);  // one wave per patch of an XCD's share
-        if (g > need) g = need;
-        if (g_rhs_lane_grid_cap > 0 && g > g_rhs_lane_grid_cap) g = (g_rhs_lane_grid_cap + 7) / 8 * 8;
-        if (g_patch_dbg & ~(64 | 32))
-            tet_rhs_lane_kernel<64, 1, true><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial, g_patch_dbg);
-        else if (wps == 2)
-            tet_rhs_lane_kernel<64, 2, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial, 0);
-        else
-            tet_rhs_lane_kernel<64, 1, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial, 0);
-    } else if (pad_tets == 64 && pad_nodes == 64)
+    else if (pad_tets == 64 && pad_nodes == 64)
         tet_rhs_wave_kernel<64, 64><<<grid, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial);
     else if (pad_tets == 16 && pad_nodes == 32)
         tet_rhs_wave_kernel<16, 32><<<grid, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, adj, adj_start, nodep, partial);
@@ -729,6 +728,32 @@ void dfl_assemble_tet_rhs_wave(I npatch, I pad_tets, I pad_nodes, const I* cnt, 
         fprintf(stderr, "dfl_assemble_tet_rhs_wave: unsupported patch shape %d tets / %d nodes\n", (int)pad_tets, (int)pad_nodes);
         abort();
     }
+    DFL_LAUNCH_CHECK();
+}
+
+// lane-per-tet kernel, persistent waves: 2 workgroups per CU (built for 2 waves per SIMD; measured 0.85 ms at 10M tets against
+// 1.07 ms for the 1-wave build and 1.29 ms for the 4-lanes-per-tet wave kernel)
+void dfl_assemble_tet_rhs_lane(I npatch, const I* cnt, const I* pnode, const unsigned char* lien, const unsigned short* sub4,
+                               const unsigned short* sub_start, const T* nodep, T* partial, void* stream) {
+    if (npatch <= 0) return;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        DFL_GUARD(hipGetDevice(&dev));
+        DFL_GUARD(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (cus < 8) cus = 8;
+    }
+    const int wps = (g_patch_dbg & 64) ? 1 : 2;  // developer A/B: bit 64 = the 1-wave-per-SIMD build (no spills, 512 registers)
+    int g = (wps * cus) / 8 * 8;
+    const int need = 8 * ((((npatch + 7) / 8) + 3) / 4);  // one wave per patch of an XCD's share
+    if (g > need) g = need;
+    if (g_rhs_lane_grid_cap > 0 && g > g_rhs_lane_grid_cap) g = (g_rhs_lane_grid_cap + 7) / 8 * 8;
+    if (g_patch_dbg & ~(64 | 32))
+        tet_rhs_lane_kernel<64, 1, true><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, g_patch_dbg);
+    else if (wps == 2)
+        tet_rhs_lane_kernel<64, 2, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0);
+    else
+        tet_rhs_lane_kernel<64, 1, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0);
     DFL_LAUNCH_CHECK();
 }
 

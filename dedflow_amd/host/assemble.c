@@ -184,7 +184,10 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
                                : DflBuildRhsPatchSchedule(mesh, x->cfg.rhspatch_leaf, x->cfg.rhspatch_nodes, 0, 0);
         const RhsPatchSched* rp = x->rhspatch;
         int slot = DflProfileBegin(DFL_TAG_ASM_RHS);
-        if (wave)
+        if (wave && rp->d_sub4 && !(dfl_tune_asm_flags() & 32))
+            dfl_assemble_tet_rhs_lane(rp->num_patch, rp->d_cnt, rp->d_pnode, rp->d_lien, rp->d_sub4, rp->d_sub_start, x->nodep,
+                                      rp->d_partial, s);
+        else if (wave)
             dfl_assemble_tet_rhs_wave(rp->num_patch, rp->pad_tets, rp->pad_nodes, rp->d_cnt, rp->d_pnode, rp->d_lien, rp->d_adj,
                                       rp->d_adj_start, x->nodep, rp->d_partial, s);
         else

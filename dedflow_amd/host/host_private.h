@@ -35,6 +35,9 @@ typedef struct RhsPatchSched {
     f64* d_partial;          /* device [total_nodes][6] */
     index_type pad_tets, pad_nodes; /* > 0: fixed-stride layout (patch p at tet slot p*pad_tets, node slot p*pad_nodes) */
     index_type* d_cnt;       /* device [P] num_tets | num_nodes << 16 */
+    /* 64-tet padded layout only (lane-per-tet kernel): the adjacency of a patch node cut into sub-lists of <= 4 entries */
+    uint16_t* d_sub4;        /* device [P][128][4] result slots (local tet * 4 + a) of each sub-list, 256 = the zero slot */
+    uint16_t* d_sub_start;   /* device [P][pad_nodes + 1] first sub-list of each patch node; entry nn = number of sub-lists */
 } RhsPatchSched;
 RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_type node_cap, index_type pad_tets, index_type pad_nodes);
 void DflFreeRhsPatchSchedule(RhsPatchSched* ps);

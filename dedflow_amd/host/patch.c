@@ -384,6 +384,16 @@ RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_typ
     uint16_t* adj = (uint16_t*)calloc(tslots * 4 + 4, sizeof(uint16_t));
     uint16_t* adj_start = (uint16_t*)calloc((size_t)totn + (size_t)P + 1, sizeof(uint16_t));
     index_type* cnt_of = (index_type*)malloc(sizeof(index_type) * (size_t)(P > 0 ? P : 1));
+    /* lane-per-tet kernel (64-tet patches): two-level ordered sum -- every sub-list has exactly 4 entries (padding = slot
+       256, which holds 0.0), so all lanes of the first level do the same work whatever the valence of their node */
+    const int sublists = padded && pad_tets == 64 && pad_nodes == 64;
+    uint16_t* sub4 = NULL;
+    uint16_t* sub_start = NULL;
+    if (sublists) {
+        sub4 = (uint16_t*)malloc(sizeof(uint16_t) * 512 * (size_t)(P > 0 ? P : 1));
+        for (size_t i = 0; i < 512 * (size_t)P; ++i) sub4[i] = 256;
+        sub_start = (uint16_t*)calloc((size_t)(pad_nodes + 1) * (size_t)(P > 0 ? P : 1), sizeof(uint16_t));
+    }
 #pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
     for (index_type p = 0; p < P; ++p) {
         const index_type lo = x.out[p].lo, ne = x.out[p].hi - lo, nn = nn_of[p];
@@ -414,6 +424,19 @@ RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_typ
                 const u8 l = lien[((size_t)eoff[p] + k) * 4 + a];
                 adj[(size_t)eoff[p] * 4 + cur[l]++] = (uint16_t)(k * 4 + a);
             }
+        if (sublists) {
+            uint16_t* s4 = sub4 + (size_t)p * 512;
+            uint16_t* ss = sub_start + (size_t)p * (size_t)(pad_nodes + 1);
+            index_type sidx = 0;
+            for (index_type k = 0; k < nn; ++k) {
+                ss[k] = (uint16_t)sidx;
+                for (index_type q = st[k]; q < st[k + 1]; q += 4, ++sidx) {
+                    ASSERT(sidx < 128);
+                    for (index_type i = 0; i < 4 && q + i < st[k + 1]; ++i) s4[sidx * 4 + i] = adj[(size_t)eoff[p] * 4 + q + i];
+                }
+            }
+            for (index_type k = nn; k <= pad_nodes; ++k) ss[k] = (uint16_t)sidx;
+        }
     }
     /* node -> its partial records (ascending patch order) */
     index_type* goff = (index_type*)calloc((size_t)N + 1, sizeof(index_type));
@@ -441,6 +464,12 @@ RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_typ
     ps->d_goff = (index_type*)CdamMallocDevice(((ptrdiff_t)N + 1) * SIZE_OF(index_type));
     ps->d_gidx = (index_type*)CdamMallocDevice((ptrdiff_t)(totn > 0 ? totn : 1) * SIZE_OF(index_type));
     ps->d_partial = (f64*)CdamMallocDevice((ptrdiff_t)(totn > 0 ? totn : 1) * 6 * SIZE_OF(f64));
+    if (sublists) {
+        ps->d_sub4 = (uint16_t*)CdamMallocDevice((ptrdiff_t)512 * (P > 0 ? P : 1) * (ptrdiff_t)sizeof(uint16_t));
+        ps->d_sub_start = (uint16_t*)CdamMallocDevice((ptrdiff_t)(pad_nodes + 1) * (P > 0 ? P : 1) * (ptrdiff_t)sizeof(uint16_t));
+        HIPGUARD(hipMemcpy(ps->d_sub4, sub4, sizeof(uint16_t) * 512 * (size_t)P, H2D));
+        HIPGUARD(hipMemcpy(ps->d_sub_start, sub_start, sizeof(uint16_t) * (size_t)(pad_nodes + 1) * (size_t)P, H2D));
+    }
     HIPGUARD(hipMemcpy(ps->d_eoff, eoff, sizeof(index_type) * ((size_t)P + 1), H2D));
     HIPGUARD(hipMemcpy(ps->d_noff, noff, sizeof(index_type) * ((size_t)P + 1), H2D));
     HIPGUARD(hipMemcpy(ps->d_pnode, pnode, sizeof(index_type) * (size_t)totn, H2D));
@@ -452,7 +481,7 @@ RhsPatchSched* DflBuildRhsPatchSchedule(Mesh3D* mesh, index_type leaf, index_typ
     if (verbose) fprintf(stderr, "[rhspatch] %d patches, %lld patch nodes (%.2f per node) in %.2f s\n", P, (long long)totn,
                          (double)totn / (double)(N > 0 ? N : 1), omp_get_wtime() - t0);
     for (index_type p = 0; p < P; ++p) free(nodes_of[p]);
-    free(cnt_of);
+    free(cnt_of); free(sub4); free(sub_start);
     free(gidx); free(goff); free(adj_start); free(adj); free(lien); free(pnode);
     free(nodes_of); free(nn_of); free(noff); free(eoff); free(x.out); free(idx); free(c);
     return ps;
@@ -463,6 +492,6 @@ void DflFreeRhsPatchSchedule(RhsPatchSched* ps) {
     CdamFreeDevice(ps->d_eoff, 0); CdamFreeDevice(ps->d_noff, 0); CdamFreeDevice(ps->d_pnode, 0);
     CdamFreeDevice(ps->d_lien, 0); CdamFreeDevice(ps->d_adj, 0); CdamFreeDevice(ps->d_adj_start, 0);
     CdamFreeDevice(ps->d_goff, 0); CdamFreeDevice(ps->d_gidx, 0); CdamFreeDevice(ps->d_cnt, 0);
-    CdamFreeDevice(ps->d_partial, 0);
+    CdamFreeDevice(ps->d_partial, 0); CdamFreeDevice(ps->d_sub4, 0); CdamFreeDevice(ps->d_sub_start, 0);
     CdamFreeHost(ps, SIZE_OF(RhsPatchSched));
 }

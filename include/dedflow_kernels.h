@@ -353,8 +353,14 @@ void dfl_assemble_tet_lhs_slot(dfl_index npatch, const int32_t* hdr, const dfl_i
 void dfl_assemble_tet_rhs_wave(dfl_index npatch, dfl_index pad_tets, dfl_index pad_nodes, const dfl_index* cnt,
                                const dfl_index* pnode, const unsigned char* lien, const unsigned short* adj,
                                const unsigned short* adj_start, const dfl_value* nodep, dfl_value* partial, void* stream);
+/* lane-per-tet form on the (64,64) shape: the adjacency as sub-lists of exactly 4 result slots (256 = zero slot),
+ * sub4[p][128][4], and sub_start[p][65] (first sub-list of each patch node; entry num_nodes.. = number of sub-lists) */
+void dfl_assemble_tet_rhs_lane(dfl_index npatch, const dfl_index* cnt, const dfl_index* pnode, const unsigned char* lien,
+                               const unsigned short* sub4, const unsigned short* sub_start, const dfl_value* nodep,
+                               dfl_value* partial, void* stream);
 /* developer probe of the patch kernel (bit 0 skip element loop, bit 1 skip flush, bit 2 skip LDS adds) */
 void dfl_tune_asm(int flags);
+int dfl_tune_asm_flags(void);
 /* weak-BC faces of one color (src/assemble.cu:1764-1964): face list entries index f2e/forn of the group */
 void dfl_assemble_face(dfl_index n_face, const dfl_index* face_list, const dfl_index* f2e, const dfl_index* forn,
                        const dfl_index* ien, dfl_index N, const dfl_value* xg, const dfl_value* wgalpha,
