@@ -607,8 +607,6 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
         // its 1-6 sub-list sums in order.  Fixed association ((a0+a1)+a2)+a3 per sub-list, then sub-lists in order.
         {
             const int ns6 = (int)s_st[w][NODES] * 6;  // entry NODES = number of sub-lists (entries >= nn repeat it)
-            const double* subv_end = nullptr;
-            (void)subv_end;
             if (!(PROBE && (dbg & 256))) {
 #pragma unroll 2
                 for (int tk = lane; tk < ns6; tk += 64) {
