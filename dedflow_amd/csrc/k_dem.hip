@@ -9,7 +9,8 @@
 //       overlap d = 2R - |xi - xj| > 0,  n = (xi - xj)/|xi - xj|
 //       F_ij = (kn * d - gn * ((vi - vj) . n)) n          acc_i = sum_j F_ij / m
 //   plus the same law against the six walls of the unit box (d = R - distance to wall).
-// Neighbour search: uniform cell list, cell edge >= 2R, particles sorted by (cell, particle id)
+// Neighbour search: uniform cell list, cell edge >= 4R (a particle's interaction range [x - 2R, x + 2R] then covers at most
+// two cells per axis), particles sorted by (cell, particle id)
 // (counting sort + per-cell ordering => fixed summation order => bitwise reproducible forces).
 // HBM-bound: (48 read + 24 write) B per particle + 24 B per tested neighbour.
 #include "dfl_common.hpp"
@@ -24,17 +25,19 @@ __device__ __forceinline__ int cell_coord(double x, double inv_cell, int ncell) 
     return c < 0 ? 0 : (c >= ncell ? ncell - 1 : c);
 }
 
-// The whole sweep is five small dependent launches on the library stream, no allocation, no host round trip:
-//   bin    cell of every particle; count[cell]++ and chunk_sum[cell / 1024]++ (integer atomics: the COUNTS are
-//          deterministic, the returned ranks are not -- the segment sort below removes that freedom)
-//   scan   cell_start = exclusive scan of count (every block adds up the chunk sums before it: one launch), count zeroed
-//   place  order[cell_start[cell] + rank] = particle; chunk sums zeroed for the next sweep
-//   sort   the first particle of every non-empty cell orders the cell's few entries by particle id (=> the neighbour
-//          loops visit particles in a FIXED order: bitwise reproducible forces) and writes the sorted copies of
+// The whole sweep is six small dependent launches on the library stream, no allocation, no host round trip:
+//   bin    cell of every particle; count[cell]++ (integer atomics: the COUNTS are deterministic, the returned ranks are
+//          not -- the segment sort below removes that freedom).  The grid is sized for a few particles per cell, so the
+//          atomics are nearly uncontended (a per-chunk counter bumped by every particle cost 18 us of serialised atomics)
+//   chunk  total of every 1024-cell chunk
+//   scan   cell_start = exclusive scan of count (every block adds up the chunk totals before it), count zeroed
+//   place  slot[cell_start[cell] + rank] = particle (arrival order)
+//   sort   every particle finds its place among the few members of its cell (number of members with a smaller id => the
+//          neighbour loops visit particles in a FIXED order: bitwise reproducible forces) and writes its own sorted copy of
 //          position / velocity, so that the force kernel streams contiguous runs instead of gathering through order[]
 //   force  one thread per sorted slot over the 9 contiguous 3-cell runs around it
 __global__ __launch_bounds__(BLK) void dem_bin_kernel(I P, const T* __restrict__ coord, T inv_cell, I ncell, I* __restrict__ cell_of,
-                                                     I* __restrict__ rank, I* __restrict__ count, I* __restrict__ chunk_sum) {
+                                                     I* __restrict__ rank, I* __restrict__ count) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= P) return;
     const int cx = cell_coord(coord[3 * i], inv_cell, ncell);
@@ -43,7 +46,6 @@ __global__ __launch_bounds__(BLK) void dem_bin_kernel(I P, const T* __restrict__
     const int c = cx + ncell * (cy + ncell * cz);
     cell_of[i] = c;
     rank[i] = atomicAdd(&count[c], 1);
-    atomicAdd(&chunk_sum[c / SCAN_CHUNK], 1);
 }
 
 // cell_start[0 .. n] = exclusive scan of count[0 .. n) (cell_start[n] = total); block b owns cells [b*1024, (b+1)*1024)
@@ -89,35 +91,45 @@ __global__ __launch_bounds__(BLK) void dem_scan_kernel(I n, I* __restrict__ coun
     }
 }
 
-__global__ __launch_bounds__(BLK) void dem_place_kernel(I P, const I* __restrict__ cell_of, const I* __restrict__ rank,
-                                                       const I* __restrict__ cell_start, I* __restrict__ order, I nchunk,
-                                                       I* __restrict__ chunk_sum) {
-    const int i = blockIdx.x * BLK + threadIdx.x;
-    if (i < nchunk) chunk_sum[i] = 0;
-    if (i >= P) return;
-    order[cell_start[cell_of[i]] + rank[i]] = i;
+// total of every 1024-cell chunk (large grids only: feeds dem_scan_kernel)
+__global__ __launch_bounds__(BLK) void dem_chunk_sum_kernel(I n, const I* __restrict__ count, I* __restrict__ chunk_sum) {
+    __shared__ int s_part[BLK];
+    const int t = threadIdx.x;
+    const long long c0 = (long long)blockIdx.x * SCAN_CHUNK + 4 * t;
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v += (c0 + k < n) ? count[c0 + k] : 0;
+    s_part[t] = v;
+    __syncthreads();
+    for (int off = BLK / 2; off > 0; off >>= 1) {
+        if (t < off) s_part[t] += s_part[t + off];
+        __syncthreads();
+    }
+    if (t == 0) chunk_sum[blockIdx.x] = s_part[0];
 }
 
-__global__ __launch_bounds__(BLK) void dem_sort_cells_kernel(I P, const I* __restrict__ cell_of, const I* __restrict__ rank,
-                                                            const I* __restrict__ cell_start, I* __restrict__ order,
+__global__ __launch_bounds__(BLK) void dem_place_kernel(I P, const I* __restrict__ cell_of, const I* __restrict__ rank,
+                                                       const I* __restrict__ cell_start, I* __restrict__ slot) {
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= P) return;
+    slot[cell_start[cell_of[i]] + rank[i]] = i;
+}
+
+__global__ __launch_bounds__(BLK) void dem_sort_cells_kernel(I P, const I* __restrict__ cell_of, const I* __restrict__ cell_start,
+                                                            const I* __restrict__ slot, I* __restrict__ order,
                                                             const T* __restrict__ coord, const T* __restrict__ vel,
                                                             T* __restrict__ sorted /*[P][6]*/) {
     const int i = blockIdx.x * BLK + threadIdx.x;
-    if (i >= P || rank[i] != 0) return;  // one thread per non-empty cell
+    if (i >= P) return;
     const int c = cell_of[i];
     const int lo = cell_start[c], hi = cell_start[c + 1];
-    for (int a = lo + 1; a < hi; ++a) {  // insertion sort of a handful of entries
-        const int key = order[a];
-        int b = a - 1;
-        while (b >= lo && order[b] > key) { order[b + 1] = order[b]; --b; }
-        order[b + 1] = key;
-    }
-    for (int a = lo; a < hi; ++a) {
-        const long long j = order[a];
-        T* o = sorted + (long long)a * 6;
-        o[0] = coord[3 * j]; o[1] = coord[3 * j + 1]; o[2] = coord[3 * j + 2];
-        o[3] = vel[3 * j]; o[4] = vel[3 * j + 1]; o[5] = vel[3 * j + 2];
-    }
+    int r = 0;
+    for (int a = lo; a < hi; ++a) r += slot[a] < i;  // a handful of members per cell
+    const long long pos = lo + r;
+    order[pos] = i;
+    T* o = sorted + pos * 6;
+    o[0] = coord[3 * i]; o[1] = coord[3 * i + 1]; o[2] = coord[3 * i + 2];
+    o[3] = vel[3 * i]; o[4] = vel[3 * i + 1]; o[5] = vel[3 * i + 2];
 }
 
 __global__ __launch_bounds__(BLK) void dem_force_kernel(I P, const T* __restrict__ sorted, T R, T mass, T kn, T gn, T inv_cell,
@@ -127,18 +139,17 @@ __global__ __launch_bounds__(BLK) void dem_force_kernel(I P, const T* __restrict
     if (s >= P) return;
     const T* me = sorted + (long long)s * 6;
     const double xi = me[0], yi = me[1], zi = me[2], ui = me[3], vi = me[4], wi = me[5];
-    const int cx = cell_coord(xi, inv_cell, ncell), cy = cell_coord(yi, inv_cell, ncell), cz = cell_coord(zi, inv_cell, ncell);
+    // cells the interaction range [x - 2R, x + 2R] touches: at most two per axis (cell edge >= 4R)
+    const double rng = 2.0 * R;
+    const int x0 = cell_coord(xi - rng, inv_cell, ncell), x1 = cell_coord(xi + rng, inv_cell, ncell);
+    const int y0 = cell_coord(yi - rng, inv_cell, ncell), y1 = cell_coord(yi + rng, inv_cell, ncell);
+    const int z0 = cell_coord(zi - rng, inv_cell, ncell), z1 = cell_coord(zi + rng, inv_cell, ncell);
     double fx = 0.0, fy = 0.0, fz = 0.0;
     const double d2max = 4.0 * R * R;
-    for (int dz = -1; dz <= 1; ++dz) {
-        const int z = cz + dz;
-        if (z < 0 || z >= ncell) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int y = cy + dy;
-            if (y < 0 || y >= ncell) continue;
-            const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < ncell ? cx + 1 : ncell - 1;
+    for (int z = z0; z <= z1; ++z) {
+        for (int y = y0; y <= y1; ++y) {
             const int c0 = x0 + ncell * (y + ncell * z), c1 = x1 + ncell * (y + ncell * z);
-            // the three x-neighbour cells are one contiguous run of the sorted copies
+            // the x-neighbour cells are one contiguous run of the sorted copies (ascending cell, then particle id)
             for (int t = cell_start[c0]; t < cell_start[c1 + 1]; ++t) {
                 if (t == s) continue;
                 const T* o = sorted + (long long)t * 6;
@@ -185,17 +196,17 @@ extern "C" {
 
 I dfl_dem_num_chunks(I ncell3) { return (I)(((long long)ncell3 + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK); }
 
-// count[ncell3 + 1] and chunk_sum[dfl_dem_num_chunks] must be zero on entry (they are again on return)
+// count[ncell3 + 1] must be zero on entry (it is again on return); chunk_sum[dfl_dem_num_chunks] and slot[P] are scratch
 void dfl_dem_build_cells(I P, const T* coord, const T* vel, T cell, I ncell, I* cell_of, I* rank, I* count, I* chunk_sum,
-                         I* cell_start, I* order, T* sorted, void* stream) {
+                         I* cell_start, I* slot, I* order, T* sorted, void* stream) {
     if (P <= 0) return;
     const I ncell3 = ncell * ncell * ncell;
     const I nchunk = dfl_dem_num_chunks(ncell3);
-    dem_bin_kernel<<<ceil_div(P, BLK), BLK, 0, S(stream)>>>(P, coord, 1.0 / cell, ncell, cell_of, rank, count, chunk_sum);
+    dem_bin_kernel<<<ceil_div(P, BLK), BLK, 0, S(stream)>>>(P, coord, 1.0 / cell, ncell, cell_of, rank, count);
+    dem_chunk_sum_kernel<<<nchunk, BLK, 0, S(stream)>>>(ncell3, count, chunk_sum);
     dem_scan_kernel<<<nchunk, BLK, 0, S(stream)>>>(ncell3, count, chunk_sum, cell_start);
-    const int n3 = P > nchunk ? P : nchunk;
-    dem_place_kernel<<<ceil_div(n3, BLK), BLK, 0, S(stream)>>>(P, cell_of, rank, cell_start, order, nchunk, chunk_sum);
-    dem_sort_cells_kernel<<<ceil_div(P, BLK), BLK, 0, S(stream)>>>(P, cell_of, rank, cell_start, order, coord, vel, sorted);
+    dem_place_kernel<<<ceil_div(P, BLK), BLK, 0, S(stream)>>>(P, cell_of, rank, cell_start, slot);
+    dem_sort_cells_kernel<<<ceil_div(P, BLK), BLK, 0, S(stream)>>>(P, cell_of, cell_start, slot, order, coord, vel, sorted);
     DFL_LAUNCH_CHECK();
 }
 

@@ -14,7 +14,7 @@ typedef struct ParticleExt {
     f64 cell;
     index_type ncell;
     /* persistent workspace of the sweep (device): nothing is allocated, freed or synchronised per sweep */
-    index_type *cell_of, *rank, *order;        /* [P] */
+    index_type *cell_of, *rank, *slot, *order;  /* [P] */
     index_type *count, *cell_start, *chunk_sum; /* [ncell^3 + 1], [ncell^3 + 1], [chunks] */
     f64* sorted;                                /* [P][6] position + velocity in (cell, id) order */
     index_type cap_particle, cap_cell;
@@ -48,7 +48,7 @@ void ParticleContextDestroy(ParticleContext* ctx) {
         ArrayDestroy(ctx->d_arr[k]);
     }
     if (x) {
-        CdamFreeDevice(x->cell_of, 0); CdamFreeDevice(x->rank, 0); CdamFreeDevice(x->order, 0); CdamFreeDevice(x->sorted, 0);
+        CdamFreeDevice(x->cell_of, 0); CdamFreeDevice(x->rank, 0); CdamFreeDevice(x->slot, 0); CdamFreeDevice(x->order, 0); CdamFreeDevice(x->sorted, 0);
         CdamFreeDevice(x->count, 0); CdamFreeDevice(x->cell_start, 0); CdamFreeDevice(x->chunk_sum, 0);
         CdamFreeHost(x, SIZE_OF(ParticleExt));
     }
@@ -84,15 +84,21 @@ void ParticleContextComputeForces(ParticleContext* ctx) {
     const f64 R = ParticleRadius(ctx);
     hipStream_t s = DflStream();
     DflRangePush("ParticleContextComputeForces");
-    index_type ncell = (index_type)floor(1.0 / (2.0 * R));
+    /* cell edge >= 4R: the interaction range of a particle covers at most two cells per axis; and not (much) finer than a few
+       particles per cell -- the scan over the cells is what an over-fine grid pays for (125^3 cells for 100k particles cost
+       14 us of scan; 58^3 cells 4 us, and the force kernel still tests only ~1.5 neighbours per particle) */
+    index_type ncell = (index_type)floor(1.0 / (4.0 * R));
+    const index_type by_count = (index_type)floor(cbrt(2.0 * (f64)P) + 0.5); /* about half a particle per cell */
+    if (ncell > by_count) ncell = by_count;
     if (ncell < 1) ncell = 1;
-    if (ncell > 256) ncell = 256; /* 2^24 cells at most (the dense cell arrays); larger cells stay valid: edge >= 2R */
-    const f64 cell = 1.0 / (f64)ncell; /* >= 2R */
+    if (ncell > 256) ncell = 256; /* 2^24 cells at most (the dense cell arrays) */
+    const f64 cell = 1.0 / (f64)ncell; /* >= 4R */
     const index_type ncell3 = ncell * ncell * ncell;
     if (x->cap_particle < P) {
-        CdamFreeDevice(x->cell_of, 0); CdamFreeDevice(x->rank, 0); CdamFreeDevice(x->order, 0); CdamFreeDevice(x->sorted, 0);
+        CdamFreeDevice(x->cell_of, 0); CdamFreeDevice(x->rank, 0); CdamFreeDevice(x->slot, 0); CdamFreeDevice(x->order, 0); CdamFreeDevice(x->sorted, 0);
         x->cell_of = (index_type*)CdamMallocDevice((ptrdiff_t)P * SIZE_OF(index_type));
         x->rank = (index_type*)CdamMallocDevice((ptrdiff_t)P * SIZE_OF(index_type));
+        x->slot = (index_type*)CdamMallocDevice((ptrdiff_t)P * SIZE_OF(index_type));
         x->order = (index_type*)CdamMallocDevice((ptrdiff_t)P * SIZE_OF(index_type));
         x->sorted = (f64*)CdamMallocDevice((ptrdiff_t)P * 6 * SIZE_OF(f64));
         x->cap_particle = P;
@@ -109,7 +115,7 @@ void ParticleContextComputeForces(ParticleContext* ctx) {
     const f64* coord = ArrayData(ParticleCTXDeviceCoord(ctx));
     const f64* vel = ArrayData(ParticleCTXDeviceVel(ctx));
     f64* acc = ArrayData(ParticleCTXDeviceAcc(ctx));
-    dfl_dem_build_cells(P, coord, vel, cell, ncell, x->cell_of, x->rank, x->count, x->chunk_sum, x->cell_start, x->order, x->sorted, s);
+    dfl_dem_build_cells(P, coord, vel, cell, ncell, x->cell_of, x->rank, x->count, x->chunk_sum, x->cell_start, x->slot, x->order, x->sorted, s);
     int slot = DflProfileBegin(DFL_TAG_SMALL + 1);
     dfl_dem_forces(P, x->sorted, R, ParticleMass(ctx), x->kn, x->gamma_n, cell, ncell, x->order, x->cell_start, acc, s);
     DflProfileEnd(slot);

@@ -399,7 +399,7 @@ void dfl_amg_prolong_add(dfl_index N, const dfl_index* agg, dfl_index Nc, const 
 dfl_index dfl_dem_num_chunks(dfl_index ncell3);
 void dfl_dem_build_cells(dfl_index P, const dfl_value* coord, const dfl_value* vel, dfl_value cell, dfl_index ncell,
                          dfl_index* cell_of, dfl_index* rank, dfl_index* count, dfl_index* chunk_sum, dfl_index* cell_start,
-                         dfl_index* order, dfl_value* sorted, void* stream);
+                         dfl_index* slot, dfl_index* order, dfl_value* sorted, void* stream);
 void dfl_dem_integrate(dfl_index P, dfl_value dt, dfl_value* coord, dfl_value* vel, const dfl_value* acc, void* stream);
 void dfl_dem_forces(dfl_index P, const dfl_value* sorted, dfl_value radius, dfl_value mass, dfl_value kn, dfl_value gamma_n,
                     dfl_value cell, dfl_index ncell, const dfl_index* order, const dfl_index* cell_start, dfl_value* acc,
