@@ -134,6 +134,10 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, 
     int4 hn = zero4, hn2 = zero4;
     if (pn < pend) { hn = hdr[2 * pn]; hn2 = hdr[2 * pn + 1]; }
     int buf = 0;
+    // the first patch's connectivity has arrived before the loop is entered: inside the loop the same registers carry the
+    // next patch's (already waited for), and the compiler merges the two states -- without this it waits at the loop top for
+    // everything older than the new list loads, i.e. for the previous patch's row stores
+    asm volatile("" ::"v"(nd.x), "v"(nd.y), "v"(nd.z), "v"(nd.w));
 
     for (;;) {
         const bool has_next = pn < pend;
@@ -253,7 +257,8 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, 
         }
         if (!has_next) break;
         nd = ndn;
-        __syncthreads();  // every wave is done with the tet records of this patch
+        __syncthreads();  // every wave is done with the tet records of this patch (an LDS-only barrier -- raw s_barrier behind
+                          // lgkmcnt(0), so that the row stores need not drain here -- was measured: no difference)
         h = hn; h2 = hn2; hn = hnn; hn2 = hnn2;
         p = pn; pn = pnn;
         buf ^= 1;
