@@ -17,8 +17,10 @@ def api():
     return A
 
 
-@pytest.mark.parametrize("P,R", [(3000, 0.03), (100000, 0.004)])
+@pytest.mark.parametrize("P,R", [(3000, 0.03), (100000, 0.004), (20000, 0.002), (300, 0.2)])
 def test_dem_forces_match_oracle(api, oracle_lib, P, R):
+    """(20000, 0.002): the grid is sized by the particle count (34^3 cells of 15 R: cells far wider than the interaction
+    range); (300, 0.2): 4R > 1/2, a single cell = all pairs."""
     x, v, _ = dem_particles(P, R)
     pc = api.Particles(x, v, R, mass=1.0, kn=1.0e4, gamma_n=1.0)
     try:
