@@ -221,7 +221,7 @@ def main():
         eq = ab["asm_lhs_colored"] * K / (prof["asm_lhs"][1] * 1e-3) / 1e9
         kernels["asm_lhs"].update({"colored_scatter_bytes_per_assembly": ab["asm_lhs_colored"],
                                    "GBps_equivalent_colored_scatter": eq, "frac_of_8TBps_equivalent_colored_scatter": eq / HBM_PEAK_GBS})
-    c, t, _ = prof["asm_rhs"]; entry("asm_rhs", ab["asm_rhs"] * K, c, t, "404*T+120N per F assembly (wave-per-patch kernel + ordered node sum: 2 launches)")
+    c, t, _ = prof["asm_rhs"]; entry("asm_rhs", ab["asm_rhs"] * K, c, t, "404*T+120N per F assembly = the colored-scatter byte model (lane-per-tet persistent wave kernel + ordered node sum: 2 launches; PMC traffic: roofline.traffic / profiles/pmc_traffic_M119.json)")
     c, t, _ = prof["pc_apply"]; entry("pc_apply", ab["pc_apply"] * c, c, t, "80N+64N per apply")
     cd, td, _ = prof["cgs_dots"]; cu, tu, _ = prof["cgs_update"]
     entry("cgs", sum(ab["cgs"]) * K, cd + cu, td + tu, "2*8*4N*(k+1)+24*4N per Arnoldi step k")

@@ -151,7 +151,14 @@ DflRcclComm* DflRcclCommCreate(const char* id128, int rank, int world) {
     memcpy(&id, id128, sizeof id);
     c->rank = rank;
     c->world = world;
-    RCCLGUARD(R.CommInitRank(&c->comm, world, id, rank));
+    {   /* a communicator that cannot be created is not fatal: the caller falls back to its torch.distributed callbacks */
+        const int rc = R.CommInitRank(&c->comm, world, id, rank);
+        if (rc != RCCL_SUCCESS) {
+            fprintf(stderr, "DflRcclCommCreate: ncclCommInitRank failed (%d: %s)\n", rc, R.GetErrorString ? R.GetErrorString(rc) : "?");
+            CdamFreeHost(c, SIZE_OF(DflRcclComm));
+            return NULL;
+        }
+    }
     c->send_count = (index_type*)CdamMallocHost(SIZE_OF(index_type) * world);
     c->recv_count = (index_type*)CdamMallocHost(SIZE_OF(index_type) * world);
     memset(c->send_count, 0, sizeof(index_type) * (size_t)world);
@@ -176,7 +183,11 @@ DflRcclComm* DflRcclCommCreate(const char* id128, int rank, int world) {
 void DflRcclCommCreateHaloComm(DflRcclComm* c, const char* id128) {
     rccl_unique_id id;
     memcpy(&id, id128, sizeof id);
-    RCCLGUARD(R.CommInitRank(&c->halo_comm, c->world, id, c->rank));
+    const int rc = R.CommInitRank(&c->halo_comm, c->world, id, c->rank);
+    if (rc != RCCL_SUCCESS) { /* not fatal: the halo traffic then shares the all-reduce communicator (never concurrent with it) */
+        fprintf(stderr, "DflRcclCommCreateHaloComm: ncclCommInitRank failed (%d), sharing the main communicator\n", rc);
+        c->halo_comm = NULL;
+    }
 }
 
 /* halo plan: send_idx / recv_idx are HOST arrays of flat dof indices into the local [u|p|..] vector,
