@@ -20,7 +20,9 @@
  * No post-smoothing: a second DILU sweep after the correction (z += S (r - A z)) stalls the 50M-tet solve at 1e-3 -- the
  * block-DILU iteration is not a convergent smoother for this stabilised (u,p) system on fine meshes, which is also why the
  * outer count still grows slowly with the mesh (16 / 17 / 28 / 38 iterations to rtol 1e-4 at M = 60 / 119 / 160 / 203;
- * DILU alone: 120 at M = 119, ~600 at M = 203), independent of the aggregate size (8 or 64) and of the inner tolerance.
+ * DILU alone: 120 at M = 119, ~600 at M = 203), independent of the aggregate size (8 or 64), of the inner tolerance and of a
+ * damping factor on the smoother step (0.5 - 1.3).  With the time step fixed the CFL number grows with the mesh (10 at M = 203
+ * for |u| = 1): the momentum block becomes advection-dominated, which a piecewise-constant coarse space does not follow.
  * Single GPU only for now.
  */
 #include <string.h>
