@@ -41,9 +41,10 @@ def test_distributed_algorithm_cpu_gloo(world, oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 5])
 def test_distributed_product_path_gpu_gloo(world, oracle_lib):
-    out = _launch("gpu", world, 8, 30)
+    """World 5 is as far as one GPU box goes (at most 6 processes may hold the card, this one included)."""
+    out = _launch("gpu", world, 10 if world == 5 else 8, 30)
     assert "DIST_GPU_OK" in out
 
 
