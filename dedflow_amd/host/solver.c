@@ -389,7 +389,8 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     if (e) ncand = atoi(e);
     if (ncand > 8) ncand = 8;
     if (getenv("DFL_VECTOR_ARENA_GB")) ncand = 1;
-    if (ncand < 2 || ws_in_pool() || !MatrixFSBlockValues(A) || ex->has_comm || m < 8 || na < (1 << 20)) return first;
+    /* (partitioned runs calibrate too: the piece of the loop that is timed is rank-local -- no collective, no halo) */
+    if (ncand < 2 || ws_in_pool() || !MatrixFSBlockValues(A) || m < 8 || na < (1 << 20)) return first;
     hipStream_t s = DflStream();
     f64* cand[8];
     int pooled[8];
