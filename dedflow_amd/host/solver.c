@@ -512,7 +512,10 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     const f64 *fj_d33 = NULL, *fj_d1 = NULL;
     index_type fj_N = 0, fj_rows = 0;
     const b32 fuse_pc = dist && ex->fused_norm && !Zb && m + 2 <= 1024 && getenv("DFL_NO_FUSED_UPDATE_PC") == NULL &&
-                        jacobi_tree_data(pc, &fj_d33, &fj_d1, &fj_N, &fj_rows) && na == 4 * fj_N && fj_rows > 0;
+                        jacobi_tree_data(pc, &fj_d33, &fj_d1, &fj_N, &fj_rows) && na == 4 * fj_N && fj_rows > 0 &&
+                        fj_rows <= 500000; /* measured: 38 us against 31 + 7 + 6 us for the three kernels at 227k owned nodes, but
+                                              274 us against 192 + 46 + 10 us at 1.73M (the node-per-thread mapping streams the
+                                              basis with 8-byte loads): large ranks keep the three launches */
     for (index_type cycle = 0; !converged && total < maxit; ++cycle) {
         f64* res_hist = ex->res_hist + total; /* history of this cycle */
         index_type iter = 0;
