@@ -66,8 +66,14 @@ def test_rccl_communicator_single_rank_gpu(oracle_lib):
 
 
 @pytest.mark.gpu
-def test_distributed_fused_norm_option_gpu_gloo(oracle_lib):
+@pytest.mark.parametrize("fused_kernel", [True, False])
+def test_distributed_fused_norm_option_gpu_gloo(oracle_lib, fused_kernel):
     """KrylovSetFusedNorm: h and w.w in ONE all-reduce per Arnoldi step, ||w - Qh|| from the Pythagorean identity; same
-    residual history as the single-domain oracle within the partitioned-run tolerance, no cancellation flag."""
-    out = _launch("gpu", 2, 8, 30, extra_env={"DFL_FUSED_NORM": "1"})
+    residual history as the single-domain oracle within the partitioned-run tolerance, no cancellation flag.  Both forms of
+    the step: update + Givens + next preconditioner application in one launch (ranks up to 500k owned nodes) and as three
+    launches (larger ranks; forced here with DFL_NO_FUSED_UPDATE_PC)."""
+    env = {"DFL_FUSED_NORM": "1"}
+    if not fused_kernel:
+        env["DFL_NO_FUSED_UPDATE_PC"] = "1"
+    out = _launch("gpu", 2, 8, 30, extra_env=env)
     assert "DIST_GPU_OK" in out
