@@ -285,7 +285,6 @@ def main():
                                "converged": bool(conv3), "ms": 1e3 * res[-1], "first_solve_incl_hierarchy_build_ms": 1e3 * res[0],
                                "relative_residual": float(hist3[-1] / r03) if len(hist3) else None, "dofs_per_s": 4.0 * N / res[-1]}
         L.KrylovSetPCType(P.ksp, api.PC_DECOMPOSITION)
-        L.KrylovSetFlexible(P.ksp, 0)
         ksp_i[0] = its
         ksp_f[1], ksp_f[2] = 0.0, 0.0
 

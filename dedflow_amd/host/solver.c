@@ -214,6 +214,7 @@ typedef struct KrylovExt {
     b32 has_comm;
     PCType pc_type; /* tree KrylovSolve builds: PC_DECOMPOSITION (reference) or PC_ILU0 */
     index_type restart; /* GMRES(m): basis columns per cycle; <= 0 or >= max_iter = full GMRES (the reference, krylov.c:56-334) */
+    b32 flexible_user; /* KrylovSetFlexible(on): FGMRES whatever the preconditioner; otherwise PC_TWOLEVEL alone switches it on */
     b32 flexible;   /* FGMRES: keep Z[:,k] = M_k^-1 Q[:,k] (a second basis) so that the preconditioner may vary from step to step */
     const Mesh3D* mesh; /* optional: node coordinates for preconditioners that aggregate nodes (PC_TWOLEVEL) */
     index_type agg_size; /* PC_TWOLEVEL: nodes per aggregate */
@@ -262,7 +263,10 @@ void KrylovSetPCType(Krylov* k, PCType type) {
 PC* KrylovGetPC(const Krylov* k) { return (PC*)k->pc; }
 void KrylovSetFusedNorm(Krylov* k, b32 on) { kext(k)->fused_norm = on; }
 void KrylovSetRestart(Krylov* k, index_type m) { kext(k)->restart = m; }
-void KrylovSetFlexible(Krylov* k, b32 on) { kext(k)->flexible = on; }
+void KrylovSetFlexible(Krylov* k, b32 on) {
+    kext(k)->flexible = on;
+    kext(k)->flexible_user = on;
+}
 void KrylovSetMesh(Krylov* k, const Mesh3D* mesh) { kext(k)->mesh = mesh; }
 void KrylovSetAggregateSize(Krylov* k, index_type nodes) { kext(k)->agg_size = nodes; }
 const DflComm* KrylovGetComm(const Krylov* k) { return kext(k)->has_comm ? &kext(k)->comm : NULL; }
@@ -746,11 +750,17 @@ void KrylovSolve(Krylov* ksp, Matrix* A, f64* x, f64* b) {
         PCDestroy(pc);
         /* convergence test every 20th iteration (krylov.c:281) -- every 4th under PC_TWOLEVEL, where an iteration costs two
            fine-level matvecs, a DILU sweep and a coarse solve and the 8-byte read nothing -- unless the caller chose */
-        if (!kext(ksp)->check_interval_set)
-            kext(ksp)->check_interval = (kext(ksp)->pc_type == PC_TWOLEVEL && MatrixFSBlockValues(A) && kext(ksp)->mesh) ? 4 : 20;
+        const b32 two_level = kext(ksp)->pc_type == PC_TWOLEVEL && MatrixFSBlockValues(A) && kext(ksp)->mesh;
+        if (!kext(ksp)->check_interval_set) kext(ksp)->check_interval = two_level ? 4 : 20;
+        /* the coarse level of PC_TWOLEVEL is solved by an inner Krylov iteration: the PC varies, the outer solver must be
+           flexible; a fixed preconditioner gets the plain recurrence back (and its Z basis freed) unless the caller asked */
+        kext(ksp)->flexible = two_level || kext(ksp)->flexible_user;
+        if (!kext(ksp)->flexible && kext(ksp)->Z) {
+            ws_vec_free_as(kext(ksp)->Z, kext(ksp)->ws_pooled);
+            kext(ksp)->Z = NULL;
+        }
         if (kext(ksp)->pc_type == PC_TWOLEVEL && MatrixFSBlockValues(A) && kext(ksp)->mesh) {
             pc = PCCreateTwoLevel(A, kext(ksp)->mesh, kext(ksp)->agg_size);
-            kext(ksp)->flexible = TRUE; /* the coarse level is solved by an inner Krylov iteration: the PC varies */
         } else if (kext(ksp)->pc_type == PC_ILU0 && MatrixFSBlockValues(A)) {
             pc = PCCreateDILU(A);
         } else if (A->type == MAT_TYPE_FS && ((MatrixFS*)A->data)->n_offset >= 4) {
