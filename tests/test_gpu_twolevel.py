@@ -108,3 +108,15 @@ def test_twolevel_iterations_do_not_grow_with_the_mesh(api):
     assert counts[(32, api.PC_TWOLEVEL)] <= counts[(16, api.PC_TWOLEVEL)] + 6, counts
     assert counts[(32, api.PC_ILU0)] >= counts[(16, api.PC_ILU0)] + 10, counts
     assert counts[(32, api.PC_TWOLEVEL)] * 2 < counts[(32, api.PC_ILU0)], counts
+
+
+def test_lifecycles_do_not_leak(api):
+    """Six problem lifecycles cycling through the three preconditioners, each with a particle context and three coupled time
+    steps: the device pool returns to empty and free VRAM does not creep (tools/probe_lifecycle_twolevel.py, own process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "probe_lifecycle_twolevel.py"), "20"], capture_output=True,
+                       text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "LIFECYCLE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
