@@ -1,0 +1,66 @@
+"""Probe (round 2): is the SpMV placement effect about WHERE the output vector lies, or about where it lies RELATIVE to the
+value array?  The 3.3 GB value array is used from the device pool (where the library keeps it) and from two plain hipMalloc
+copies; the output vector from the pool and from plain hipMalloc blocks; every pair is timed (groups of 6 launches, median
+of 5 groups, default SpMV variant and the no-store variant)."""
+import sys, os, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dedflow_amd import api
+from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 119
+mesh = kuhn_cube(M, jitter=0.2)
+wg, dwg = synthetic_fields(mesh)
+P = api.Problem(mesh)
+L = api.lib()
+vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+L.dfl_tune.argtypes = [C.c_int, C.c_int]
+L.dfl_bcsr_spmv.argtypes = [i32, vp, vp, vp, f64, vp, f64, vp, vp]
+L.DflDeviceMalloc.restype = vp; L.DflDeviceMalloc.argtypes = [i64]
+wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+P.assemble_system(wg_d, dwg_d, None, want_J=True)
+N = P.N
+rp_h, ci_h = P.pattern()
+rp = api.DeviceArray.from_numpy(rp_h.astype(np.int32)); ci = api.DeviceArray.from_numpy(ci_h.astype(np.int32))
+nval = P.nnz1 * 16
+val_pool = L.MatrixFSBlockValues(P.J)
+hip = api.hip()
+hip.hipMemcpy.argtypes = [vp, vp, C.c_size_t, C.c_int]
+vals = [("val in the pool (library)", val_pool)]
+keep = []
+for i in range(2):
+    blk = api.DeviceArray(nval)
+    hip.hipMemcpy(blk.ptr, val_pool, 8 * nval, 3)
+    keep.append(blk)
+    vals.append(("val in hipMalloc copy #%d" % i, blk.ptr))
+    keep.append(api.DeviceArray(5000011 * (i + 1)))
+second_pool = L.DflDeviceMalloc(8 * nval)
+hip.hipMemcpy(second_pool, val_pool, 8 * nval, 3)
+vals.append(("val as a 2nd pool block", second_pool))
+x = api.DeviceArray.from_numpy(np.random.default_rng(0).normal(size=6 * N))
+ys = [("y pool #0", api.DeviceArray(6 * N, np.float64, ptr=L.DflDeviceMalloc(8 * 6 * N))),
+      ("y pool #1", api.DeviceArray(6 * N, np.float64, ptr=L.DflDeviceMalloc(8 * 6 * N)))]
+for i in range(3):
+    ys.append(("y hipMalloc #%d" % i, api.DeviceArray(6 * N)))
+    keep.append(api.DeviceArray(1000003 * (i + 1)))
+t = api.Timer()
+
+
+def run(v, y, variant):
+    L.dfl_tune(0, variant)
+    L.dfl_bcsr_spmv(N, rp.ptr, ci.ptr, v, 1.0, x.ptr, 0.0, y.ptr, None)
+    res = []
+    for g in range(5):
+        t.start()
+        for _ in range(6):
+            L.dfl_bcsr_spmv(N, rp.ptr, ci.ptr, v, 1.0, x.ptr, 0.0, y.ptr, None)
+        t.stop(); res.append(t.ms() / 6)
+    return float(np.median(res))
+
+
+print("%-28s %18s | " % ("value array", "address") + " | ".join("%-16s" % n for n, _ in ys) + " | no store")
+for vn, v in vals:
+    row = ["%.4f" % run(v, y, 4) for _, y in ys]
+    print("%-28s %#18x | " % (vn, v) + " | ".join("%-16s" % r for r in row) + " | %.4f" % run(v, ys[0][1], 5), flush=True)
+print("y addresses: " + ", ".join("%s %#x" % (n, y.ptr) for n, y in ys))
+L.dfl_tune(0, 4)
+P.close()
