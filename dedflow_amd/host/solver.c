@@ -383,12 +383,12 @@ static void pc_apply_fused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64*
  * temporaries were freed from) makes every SpMV of the Arnoldi loop that writes into it take 0.70 ms, the other five
  * 0.59 ms -- a property of the allocation, stable over time, independent of where the input vector lies, and invisible to
  * back-to-back SpMV launches (it only shows between the other kernels of the loop).  So when a new basis is allocated for a
- * block-mode matrix, up to DFL_WS_CANDIDATES (default 4, 1 = off) candidates are allocated side by side, a short piece of
+ * block-mode matrix, up to DFL_WS_CANDIDATES (default 5, 1 = off) candidates are allocated side by side, a short piece of
  * the real loop (CGS over 6 columns, preconditioner, SpMV into the next column) runs in each with the SpMV timed by
  * hipEvents on the library stream, the fastest candidate is kept and the others are freed.  A few tens of milliseconds
  * once per work-space size; skipped when device memory is short or the basis is tiny. */
 static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_t count, index_type na, index_type m, index_type ldh) {
-    int ncand = 4;
+    int ncand = 5;
     const char* e = getenv("DFL_WS_CANDIDATES");
     if (e) ncand = atoi(e);
     if (ncand > 8) ncand = 8;
@@ -410,7 +410,15 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
            differs from process to process (the value array sits in the pool; measured both ways round) */
         pooled[n] = (n == 1 && !ex->q_pooled && DflDevicePoolEnabled());
         if (pooled[n]) p = CdamMallocDevice(count * SIZE_OF(f64));
-        else if (hipMalloc(&p, (size_t)count * sizeof(f64)) != hipSuccess) { (void)hipGetLastError(); break; }
+        else if (n == ncand - 1 && ncand >= 5) {
+            /* the last candidate lies far from everything allocated so far: behind a spacer of a third of the free memory,
+               which is released again at once (whole processes were seen in which every block near the value array was slow) */
+            void* spacer = NULL;
+            if (hipMalloc(&spacer, free_b / 3) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
+            if (hipMalloc(&p, (size_t)count * sizeof(f64)) != hipSuccess) { (void)hipGetLastError(); p = NULL; }
+            if (spacer) HIPGUARD(hipFree(spacer));
+            if (!p) break;
+        } else if (hipMalloc(&p, (size_t)count * sizeof(f64)) != hipSuccess) { (void)hipGetLastError(); break; }
         HIPGUARD(hipMemsetAsync(p, 0, (size_t)count * sizeof(f64), s));
         cand[n] = (f64*)p;
     }

@@ -25,9 +25,10 @@ nval = P.nnz1 * 16
 val_pool = L.MatrixFSBlockValues(P.J)
 hip = api.hip()
 hip.hipMemcpy.argtypes = [vp, vp, C.c_size_t, C.c_int]
+hip.hipMalloc.argtypes = [C.POINTER(vp), C.c_size_t]
 vals = [("val in the pool (library)", val_pool)]
 keep = []
-for i in range(2):
+for i in range(int(os.environ.get('DFL_R2F_COPIES', '2'))):
     blk = api.DeviceArray(nval)
     hip.hipMemcpy(blk.ptr, val_pool, 8 * nval, 3)
     keep.append(blk)
@@ -42,6 +43,24 @@ ys = [("y pool #0", api.DeviceArray(6 * N, np.float64, ptr=L.DflDeviceMalloc(8 *
 for i in range(3):
     ys.append(("y hipMalloc #%d" % i, api.DeviceArray(6 * N)))
     keep.append(api.DeviceArray(1000003 * (i + 1)))
+# other allocation kinds for the output vector (hipExtMallocWithFlags): fine-grained, uncached, physically contiguous
+hip.hipExtMallocWithFlags.argtypes = [C.POINTER(vp), C.c_size_t, C.c_uint]
+for nm, fl in (("y finegrained", 0x1), ("y uncached", 0x3), ("y contiguous", 0x4)):
+    pp = vp(0)
+    rc = hip.hipExtMallocWithFlags(C.byref(pp), 8 * 6 * N, fl)
+    if rc == 0 and pp.value:
+        hip.hipMemset(pp, 0, 8 * 6 * N)
+        ys.append((nm, api.DeviceArray(6 * N, np.float64, ptr=pp.value)))
+    else:
+        print("hipExtMallocWithFlags(%#x) failed: %d" % (fl, rc))
+# output vectors allocated behind big spacers (do "regions" follow the physical distance from the value array?)
+spacers = []
+for gb in (40, 40, 40, 40):
+    sp = vp(0)
+    if hip.hipMalloc(C.byref(sp), gb << 30) != 0:
+        break
+    spacers.append(sp)
+    ys.append(("y after %d GB" % (40 * len(spacers)), api.DeviceArray(6 * N)))
 t = api.Timer()
 
 
