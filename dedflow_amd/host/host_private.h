@@ -148,4 +148,6 @@ void DflRangePop(void);
 
 int DflDevicePoolEnabled(void); /* the default DEVICE allocator carves large requests out of its pool */
 
+void DflMatrixFSRelocateBlockValues(Matrix* m, value_type* new_val); /* host/matrix.c */
+
 #endif

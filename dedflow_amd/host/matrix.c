@@ -363,7 +363,8 @@ void MatrixFSDestroy(Matrix* m) {
     index_type n = fs->n_offset;
     for (index_type i = 0; i < n * n; ++i)
         if (fs->mat[i]) MatrixDestroy(fs->mat[i]);
-    CdamFreeDevice(fs->block_val, 0);
+    if (fs->block_val_heap) { if (fs->block_val) HIPGUARD(hipFree(fs->block_val)); }
+    else CdamFreeDevice(fs->block_val, 0);
     CdamFreeHost(fs->offset, 0);
     CdamFreeDevice(fs->d_offset, 0);
     CdamFreeDevice(fs->d_matval, 0);
@@ -510,4 +511,18 @@ void MatrixAddValueBlockedBatched(Matrix* mat, index_type nb, const index_type* 
                                   index_type bc, const value_type* A, int lda, int stride) {
     ASSERT(mat && "Matrix is NULL");
     MATRIX_CALL(mat, add_value_blocked_batched, nb, brow, bcol, br, bc, A, lda, stride);
+}
+
+/* Move the 4x4-block value array of a block-mode MatrixFS into `new_val` (a plain hipMalloc block the matrix then owns);
+   the values are copied on the library stream, the old array is released.  Used by the placement calibration of the
+   Krylov solver: every consumer reads fs->block_val at call time, nothing caches the pointer. */
+void DflMatrixFSRelocateBlockValues(Matrix* m, value_type* new_val) {
+    MatrixFS* fs = fs_of(m);
+    ASSERT(fs->block_mode && fs->block_val && new_val);
+    HIPGUARD(hipMemcpyAsync(new_val, fs->block_val, (size_t)fs->spy1x1->nnz * 16 * sizeof(value_type), D2D, DflStream()));
+    HIPGUARD(hipStreamSynchronize(DflStream()));
+    if (fs->block_val_heap) HIPGUARD(hipFree(fs->block_val));
+    else CdamFreeDevice(fs->block_val, 0);
+    fs->block_val = new_val;
+    fs->block_val_heap = TRUE;
 }

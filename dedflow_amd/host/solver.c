@@ -383,12 +383,12 @@ static void pc_apply_fused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64*
  * temporaries were freed from) makes every SpMV of the Arnoldi loop that writes into it take 0.70 ms, the other five
  * 0.59 ms -- a property of the allocation, stable over time, independent of where the input vector lies, and invisible to
  * back-to-back SpMV launches (it only shows between the other kernels of the loop).  So when a new basis is allocated for a
- * block-mode matrix, up to DFL_WS_CANDIDATES (default 5, 1 = off) candidates are allocated side by side, a short piece of
+ * block-mode matrix, up to DFL_WS_CANDIDATES (default 6, 1 = off) candidates are allocated side by side, a short piece of
  * the real loop (CGS over 6 columns, preconditioner, SpMV into the next column) runs in each with the SpMV timed by
  * hipEvents on the library stream, the fastest candidate is kept and the others are freed.  A few tens of milliseconds
  * once per work-space size; skipped when device memory is short or the basis is tiny. */
 static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_t count, index_type na, index_type m, index_type ldh) {
-    int ncand = 5;
+    int ncand = 6;
     const char* e = getenv("DFL_WS_CANDIDATES");
     if (e) ncand = atoi(e);
     if (ncand > 8) ncand = 8;
@@ -410,11 +410,12 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
            differs from process to process (the value array sits in the pool; measured both ways round) */
         pooled[n] = (n == 1 && !ex->q_pooled && DflDevicePoolEnabled());
         if (pooled[n]) p = CdamMallocDevice(count * SIZE_OF(f64));
-        else if (n == ncand - 1 && ncand >= 5) {
-            /* the last candidate lies far from everything allocated so far: behind a spacer of a third of the free memory,
-               which is released again at once (whole processes were seen in which every block near the value array was slow) */
+        else if (n >= 4 && ncand >= 5) {
+            /* candidates 4, 5: far from everything allocated so far -- behind a spacer of a quarter / half of the free
+               memory, released again at once (in whole processes every block near the value array was slow: 0.72 ms, and
+               the far block 0.65 ms) */
             void* spacer = NULL;
-            if (hipMalloc(&spacer, free_b / 3) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
+            if (hipMalloc(&spacer, n == 4 ? free_b / 4 : free_b / 2) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
             if (hipMalloc(&p, (size_t)count * sizeof(f64)) != hipSuccess) { (void)hipGetLastError(); p = NULL; }
             if (spacer) HIPGUARD(hipFree(spacer));
             if (!p) break;
@@ -430,30 +431,83 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     HIPGUARD(hipMemcpyAsync(ex->nrm, &one, sizeof one, H2D, s));
     HIPGUARD(hipMemsetAsync(ex->H, 0, (size_t)ldh * sizeof(f64), s));
     int best = 0;
-    for (int k = 0; k < n; ++k) {
-        f64* Q = cand[k];
-        f64 *w = Q + (size_t)6 * (size_t)na, *y = Q + (size_t)7 * (size_t)na;
-        best_ms[k] = 1e30f;
-        for (int rep = 0; rep < 4; ++rep) {
-            float ms = 0.f;
-            dfl_cgs_dots(na, 6, Q, na, w, ex->H, ex->work, s);
-            dfl_cgs_update(na, 6, Q, na, ex->H, w, ex->nrm + 1, 1, ex->work, s);
-            pc_apply_fused(pc, na, w, ex->nrm, ex->tmp);
-            HIPGUARD(hipEventRecord(a, s));
-            MatrixMatVec(A, ex->tmp, y);
-            HIPGUARD(hipEventRecord(b, s));
-            HIPGUARD(hipEventSynchronize(b));
-            HIPGUARD(hipEventElapsedTime(&ms, a, b));
-            if (rep > 0 && ms < best_ms[k]) best_ms[k] = ms;
-        }
-        if (best_ms[k] < best_ms[best]) best = k;
+#define TIME_CANDIDATES(out_ms)                                                                      \
+    for (int k = 0; k < n; ++k) {                                                                    \
+        f64* Qk = cand[k];                                                                           \
+        f64 *w = Qk + (size_t)6 * (size_t)na, *y = Qk + (size_t)7 * (size_t)na;                      \
+        out_ms[k] = 1e30f;                                                                           \
+        for (int rep = 0; rep < 4; ++rep) {                                                          \
+            float ms = 0.f;                                                                          \
+            dfl_cgs_dots(na, 6, Qk, na, w, ex->H, ex->work, s);                                      \
+            dfl_cgs_update(na, 6, Qk, na, ex->H, w, ex->nrm + 1, 1, ex->work, s);                    \
+            pc_apply_fused(pc, na, w, ex->nrm, ex->tmp);                                             \
+            HIPGUARD(hipEventRecord(a, s));                                                          \
+            MatrixMatVec(A, ex->tmp, y);                                                             \
+            HIPGUARD(hipEventRecord(b, s));                                                          \
+            HIPGUARD(hipEventSynchronize(b));                                                        \
+            HIPGUARD(hipEventElapsedTime(&ms, a, b));                                                \
+            if (rep > 0 && ms < out_ms[k]) out_ms[k] = ms;                                           \
+        }                                                                                            \
     }
+    TIME_CANDIDATES(best_ms)
+    for (int k = 1; k < n; ++k)
+        if (best_ms[k] < best_ms[best]) best = k;
+    const int best_in_place = best;
+    /* The value array has a placement of its own: whole processes were measured in which the SpMV took 0.67 ms with the
+       array where the allocator's pool put it, whatever the output vector, and 0.57 ms with a plain hipMalloc copy
+       (tools/probe_spmv_r2f.py).  So the same piece of the loop is timed once more on a heap copy of the values, and the
+       matrix moves there if that is at least 3 % faster (DFL_VAL_RELOCATE=0 keeps it where it is). */
+    float moved_ms[2][8];
+    int moved = 0, moved_tested = 0;
+    {
+        MatrixFS* fs = (MatrixFS*)A->data;
+        const size_t vbytes = (size_t)fs->spy1x1->nnz * 16 * sizeof(f64);
+        size_t free_b = 0, total_b = 0;
+        const char* ev = getenv("DFL_VAL_RELOCATE");
+        if (!(ev && atoi(ev) == 0) && !fs->block_val_heap && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+            free_b > 3 * vbytes + ((size_t)4 << 30)) {
+            f64* const old = fs->block_val;
+            void* hv[2] = {NULL, NULL}; /* a plain block, and one behind a spacer of a third of the free memory */
+            float hv_best[2] = {1e30f, 1e30f};
+            int hv_k[2] = {0, 0};
+            for (int v = 0; v < 2; ++v) {
+                void* spacer = NULL;
+                if (v == 1 && hipMalloc(&spacer, free_b / 3) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
+                if (hipMalloc(&hv[v], vbytes) != hipSuccess) { (void)hipGetLastError(); hv[v] = NULL; }
+                if (spacer) HIPGUARD(hipFree(spacer));
+                if (!hv[v]) continue;
+                HIPGUARD(hipMemcpyAsync(hv[v], old, vbytes, D2D, s));
+                fs->block_val = (f64*)hv[v]; /* timed in place of the original; nothing else runs meanwhile */
+                TIME_CANDIDATES(moved_ms[v])
+                fs->block_val = old;
+                moved_tested |= 1 << v;
+                for (int k = 0; k < n; ++k)
+                    if (moved_ms[v][k] < hv_best[v]) { hv_best[v] = moved_ms[v][k]; hv_k[v] = k; }
+            }
+            const int vb = hv_best[1] < hv_best[0] ? 1 : 0;
+            if (hv[vb] && hv_best[vb] < 0.97f * best_ms[best]) {
+                DflMatrixFSRelocateBlockValues(A, (f64*)hv[vb]);
+                best = hv_k[vb];
+                moved = 1 + vb;
+                hv[vb] = NULL;
+            }
+            for (int v = 0; v < 2; ++v)
+                if (hv[v]) HIPGUARD(hipFree(hv[v]));
+        }
+    }
+#undef TIME_CANDIDATES
     HIPGUARD(hipEventDestroy(a));
     HIPGUARD(hipEventDestroy(b));
     if (getenv("DFL_WS_VERBOSE")) {
         fprintf(stderr, "[krylov] basis placement: in-loop SpMV into %d candidates:", n);
-        for (int k = 0; k < n; ++k) fprintf(stderr, " %.4f%s%s", best_ms[k], pooled[k] ? "(pool)" : "", k == best ? "*" : "");
+        for (int k = 0; k < n; ++k) fprintf(stderr, " %.4f%s%s", best_ms[k], pooled[k] ? "(pool)" : "", k == best_in_place ? "*" : "");
         fprintf(stderr, " ms\n");
+        for (int v = 0; v < 2; ++v)
+            if (moved_tested & (1 << v)) {
+                fprintf(stderr, "[krylov] value array on a %s heap copy:", v ? "far" : "plain");
+                for (int k = 0; k < n; ++k) fprintf(stderr, " %.4f", moved_ms[v][k]);
+                fprintf(stderr, " ms%s\n", moved == 1 + v ? " -> moved there" : "");
+            }
     }
     HIPGUARD(hipStreamSynchronize(s));
     for (int k = 0; k < n; ++k)

@@ -275,6 +275,8 @@ struct MatrixFS {
     value_type* block_val; /* [nnz1][16] device, 4x4 blocks over spy1x1 */
     index_type owned_rows; /* node rows this rank owns (== spy1x1->num_row on one GPU): SpMV / PC run on these only */
     b32 reference_layout;  /* MatrixFSUseReferenceLayout: keep the four row-expanded sub-matrix arrays (no block mode) */
+    b32 block_val_heap;    /* block_val is a plain hipMalloc block (moved out of the allocator's pool by the Krylov placement
+                              calibration, host/solver.c) -- MatrixDestroy frees it accordingly */
 };
 Matrix* MatrixCreateTypeCSR(const CSRAttr* attr, void*);
 Matrix* MatrixCreateTypeFS(index_type n_offset, const index_type* offset, void*);

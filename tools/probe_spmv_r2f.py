@@ -81,5 +81,15 @@ for vn, v in vals:
     row = ["%.4f" % run(v, y, 4) for _, y in ys]
     print("%-28s %#18x | " % (vn, v) + " | ".join("%-16s" % r for r in row) + " | %.4f" % run(v, ys[0][1], 5), flush=True)
 print("y addresses: " + ", ".join("%s %#x" % (n, y.ptr) for n, y in ys))
+# the same with the INPUT vector in each class (value array where the library keeps it)
+xs = [("x pool", api.DeviceArray(6 * N, np.float64, ptr=L.DflDeviceMalloc(8 * 6 * N))), ("x hipMalloc", api.DeviceArray(6 * N))]
+hip.hipMemcpy(xs[0][1].ptr, x.ptr, 8 * 6 * N, 3)
+hip.hipMemcpy(xs[1][1].ptr, x.ptr, 8 * 6 * N, 3)
+x_keep = x
+for xn, xv in xs:
+    x = xv
+    row = ["%.4f" % run(val_pool, y, 4) for _, y in ys[:5]]
+    print("%-28s %#18x | " % (xn + " (val in the pool)", xv.ptr) + " | ".join("%-16s" % r for r in row), flush=True)
+x = x_keep
 L.dfl_tune(0, 4)
 P.close()
