@@ -431,13 +431,17 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     HIPGUARD(hipMemcpyAsync(ex->nrm, &one, sizeof one, H2D, s));
     HIPGUARD(hipMemsetAsync(ex->H, 0, (size_t)ldh * sizeof(f64), s));
     int best = 0;
+    /* the SpMV output goes to three columns spread over the block (a block is not always of one kind from end to end);
+       a candidate's score is the mean of the three */
 #define TIME_CANDIDATES(out_ms)                                                                      \
     for (int k = 0; k < n; ++k) {                                                                    \
         f64* Qk = cand[k];                                                                           \
-        f64 *w = Qk + (size_t)6 * (size_t)na, *y = Qk + (size_t)7 * (size_t)na;                      \
-        out_ms[k] = 1e30f;                                                                           \
+        f64* w = Qk + (size_t)6 * (size_t)na;                                                        \
+        float sum_ms = 0.f;                                                                          \
         for (int rep = 0; rep < 4; ++rep) {                                                          \
             float ms = 0.f;                                                                          \
+            const index_type col = rep <= 1 ? 7 : (rep == 2 ? 7 + (m - 7) / 2 : m);                  \
+            f64* y = Qk + (size_t)col * (size_t)na;                                                  \
             dfl_cgs_dots(na, 6, Qk, na, w, ex->H, ex->work, s);                                      \
             dfl_cgs_update(na, 6, Qk, na, ex->H, w, ex->nrm + 1, 1, ex->work, s);                    \
             pc_apply_fused(pc, na, w, ex->nrm, ex->tmp);                                             \
@@ -446,8 +450,9 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
             HIPGUARD(hipEventRecord(b, s));                                                          \
             HIPGUARD(hipEventSynchronize(b));                                                        \
             HIPGUARD(hipEventElapsedTime(&ms, a, b));                                                \
-            if (rep > 0 && ms < out_ms[k]) out_ms[k] = ms;                                           \
+            if (rep > 0) sum_ms += ms;                                                               \
         }                                                                                            \
+        out_ms[k] = sum_ms / 3.f;                                                                    \
     }
     TIME_CANDIDATES(best_ms)
     for (int k = 1; k < n; ++k)
