@@ -2,7 +2,7 @@
  * (read the HDF5 mesh, build the (u,p) field-split matrix, color the mesh, set the four Dirichlet groups, run the
  * generalized-alpha time loop, write sol.<k>.h5).  It is the drop-in claim in executable form: no Python, no HIP call,
  * no kernel launcher -- only the object API the reference's own host code uses.
- *   usage: dedflow_main <mesh.h5> <sol.0.h5> <out prefix> <steps> <newton iterations>
+ *   usage: dedflow_main <mesh.h5> <sol.0.h5> <out prefix> <steps> <newton iterations> [jacobi|ilu0|twolevel]
  * Test infrastructure (tests/test_gpu_c_driver.py builds and runs it); not part of the library. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -11,7 +11,7 @@
 
 int main(int argc, char** argv) {
     if (argc < 6) {
-        fprintf(stderr, "usage: %s mesh.h5 sol.0.h5 out_prefix steps newton_its\n", argv[0]);
+        fprintf(stderr, "usage: %s mesh.h5 sol.0.h5 out_prefix steps newton_its [jacobi|ilu0|twolevel]\n", argv[0]);
         return 2;
     }
     const int nstep = atoi(argv[4]), newton = atoi(argv[5]);
@@ -40,6 +40,10 @@ int main(int argc, char** argv) {
     MatrixSetup(J);
 
     Krylov* ksp = KrylovCreateGMRES(120, 1e-12, 1e-4, NULL);
+    /* the reference's tree (krylov.c:439-453) unless asked otherwise; the two build-defined preconditioners need one call
+       each (SolveFlowSystem hands PC_TWOLEVEL the mesh itself) */
+    if (argc > 6 && strcmp(argv[6], "ilu0") == 0) KrylovSetPCType(ksp, PC_ILU0);
+    if (argc > 6 && strcmp(argv[6], "twolevel") == 0) KrylovSetPCType(ksp, PC_TWOLEVEL);
     Mesh3DGenerateColorBatch(mesh);
 
     /* boundary conditions (main.c:454-476) */

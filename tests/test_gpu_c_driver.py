@@ -50,3 +50,11 @@ def test_c_host_program_time_step_matches_oracle_driver(tmp_path, oracle_lib):
                       ("dphi", dwgold_o[4 * N:5 * N]), ("dT", dwgold_o[5 * N:])):
         got = h5.read_dataset(sol1, name, np.float64)
         assert np.abs(got - ref).max() <= 1e-7 * max(np.abs(ref).max(), 1e-300), name
+    # the same program with the two build-defined preconditioners (one KrylovSetPCType call each): every solve reaches the
+    # same tolerance, so the solution files agree to the solver's accuracy
+    for pc in ("ilu0", "twolevel"):
+        pref = str(tmp_path / ("sol_" + pc))
+        out = subprocess.run([exe, mesh_file, sol0, pref, "1", "2", pc], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        up = h5.read_dataset(pref + ".1.h5", "u", np.float64)
+        assert np.abs(up - u).max() <= 2e-3 * np.abs(u).max(), (pc, np.abs(up - u).max() / np.abs(u).max())
