@@ -6,6 +6,7 @@
  * (works for any num_part, not only powers of two). */
 #include <string.h>
 #include "dedflow.h"
+#include "rcb.h"
 
 static void centroid_bbox(const f64* c, const index_type* idx, index_type n, f64* lo, f64* hi) {
     for (int d = 0; d < 3; ++d) { lo[d] = 1e300; hi[d] = -1e300; }
@@ -18,22 +19,6 @@ static void centroid_bbox(const f64* c, const index_type* idx, index_type n, f64
 }
 
 /* quickselect on (coordinate, id) keys so that ties are broken deterministically */
-static int key_less(const f64* c, int ax, index_type a, index_type b) {
-    f64 va = c[(size_t)a * 3 + ax], vb = c[(size_t)b * 3 + ax];
-    return va < vb || (va == vb && a < b);
-}
-static void select_kth(const f64* c, int ax, index_type* idx, index_type n, index_type k) {
-    index_type lo = 0, hi = n - 1;
-    while (lo < hi) {
-        index_type p = idx[lo + (hi - lo) / 2], i = lo, j = hi;
-        while (i <= j) {
-            while (key_less(c, ax, idx[i], p)) ++i;
-            while (key_less(c, ax, p, idx[j])) --j;
-            if (i <= j) { index_type t = idx[i]; idx[i] = idx[j]; idx[j] = t; ++i; --j; }
-        }
-        if (k <= j) hi = j; else if (k >= i) lo = i; else return;
-    }
-}
 
 static void rcb(const f64* c, index_type* idx, index_type n, index_type part0, index_type nparts, index_type* epart) {
     if (nparts <= 1 || n == 0) {

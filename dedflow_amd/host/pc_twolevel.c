@@ -30,6 +30,7 @@
 #include "dedflow.h"
 #include "dedflow_kernels.h"
 #include "host_private.h"
+#include "rcb.h"
 
 typedef struct PCTwoLevel {
     Matrix* A;
@@ -56,22 +57,6 @@ static PC* tl_create(Matrix* mat, const f64* xyz, f64* xyz_owned, index_type agg
 typedef struct { index_type lo, hi; } Range;
 typedef struct { const f64* c; index_type* idx; index_type leaf; Range* out; index_type nout, capout; } Rcb;
 
-static int key_less(const f64* c, int ax, index_type a, index_type b) {
-    f64 va = c[(size_t)a * 3 + ax], vb = c[(size_t)b * 3 + ax];
-    return va < vb || (va == vb && a < b);
-}
-static void select_kth(const f64* c, int ax, index_type* idx, index_type n, index_type k) {
-    index_type lo = 0, hi = n - 1;
-    while (lo < hi) {
-        index_type p = idx[lo + (hi - lo) / 2], i = lo, j = hi;
-        while (i <= j) {
-            while (key_less(c, ax, idx[i], p)) ++i;
-            while (key_less(c, ax, p, idx[j])) --j;
-            if (i <= j) { index_type t = idx[i]; idx[i] = idx[j]; idx[j] = t; ++i; --j; }
-        }
-        if (k <= j) hi = j; else if (k >= i) lo = i; else return;
-    }
-}
 static void rcb_emit(Rcb* x, index_type lo, index_type hi) {
 #pragma omp critical(dfl_twolevel_emit)
     {

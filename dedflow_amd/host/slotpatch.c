@@ -26,6 +26,7 @@
 #include "dedflow.h"
 #include "dedflow_kernels.h"
 #include "host_private.h"
+#include "rcb.h"
 
 #define SPLIT_MIN 12              /* contributions from which a (diagonal) slot is cut into four quads */
 #define SLOT_LEADER 0x40000000    /* slot_nz flag: first quad of a split slot (sums the four quads, stores the line) */
@@ -43,22 +44,6 @@ typedef struct {
     index_type nout, capout;
 } Ctx;
 
-static int key_less(const f64* c, int ax, index_type a, index_type b) {
-    f64 va = c[(size_t)a * 3 + ax], vb = c[(size_t)b * 3 + ax];
-    return va < vb || (va == vb && a < b);
-}
-static void select_kth(const f64* c, int ax, index_type* idx, index_type n, index_type k) {
-    index_type lo = 0, hi = n - 1;
-    while (lo < hi) {
-        index_type p = idx[lo + (hi - lo) / 2], i = lo, j = hi;
-        while (i <= j) {
-            while (key_less(c, ax, idx[i], p)) ++i;
-            while (key_less(c, ax, p, idx[j])) --j;
-            if (i <= j) { index_type t = idx[i]; idx[i] = idx[j]; idx[j] = t; ++i; --j; }
-        }
-        if (k <= j) hi = j; else if (k >= i) lo = i; else return;
-    }
-}
 static int cmp_i32(const void* a, const void* b) {
     index_type x = *(const index_type*)a, y = *(const index_type*)b;
     return (x > y) - (x < y);
