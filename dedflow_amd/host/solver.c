@@ -431,16 +431,16 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     HIPGUARD(hipMemcpyAsync(ex->nrm, &one, sizeof one, H2D, s));
     HIPGUARD(hipMemsetAsync(ex->H, 0, (size_t)ldh * sizeof(f64), s));
     int best = 0;
-    /* the SpMV output goes to three columns spread over the block (a block is not always of one kind from end to end);
-       a candidate's score is the mean of the three */
+    /* the SpMV output goes to eight columns spread over the block (a block is not always of one kind from end to end: with
+       three sample columns a candidate scored 0.604 ms and then ran at 0.643 ms); a candidate's score is their mean */
 #define TIME_CANDIDATES(out_ms)                                                                      \
     for (int k = 0; k < n; ++k) {                                                                    \
         f64* Qk = cand[k];                                                                           \
         f64* w = Qk + (size_t)6 * (size_t)na;                                                        \
         float sum_ms = 0.f;                                                                          \
-        for (int rep = 0; rep < 4; ++rep) {                                                          \
+        for (int rep = 0; rep < 9; ++rep) {                                                          \
             float ms = 0.f;                                                                          \
-            const index_type col = rep <= 1 ? 7 : (rep == 2 ? 7 + (m - 7) / 2 : m);                  \
+            const index_type col = rep == 0 ? 7 : 7 + (index_type)(((int64_t)(m - 7) * (rep - 1)) / 7); \
             f64* y = Qk + (size_t)col * (size_t)na;                                                  \
             dfl_cgs_dots(na, 6, Qk, na, w, ex->H, ex->work, s);                                      \
             dfl_cgs_update(na, 6, Qk, na, ex->H, w, ex->nrm + 1, 1, ex->work, s);                    \
@@ -452,7 +452,7 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
             HIPGUARD(hipEventElapsedTime(&ms, a, b));                                                \
             if (rep > 0) sum_ms += ms;                                                               \
         }                                                                                            \
-        out_ms[k] = sum_ms / 3.f;                                                                    \
+        out_ms[k] = sum_ms / 8.f;                                                                    \
     }
     TIME_CANDIDATES(best_ms)
     for (int k = 1; k < n; ++k)
