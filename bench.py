@@ -103,8 +103,8 @@ def cpu_baseline(M_sample, its):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--M", type=int, default=119, help="cells per cube edge (119 -> 10.1M tets)")
     ap.add_argument("--gmres-its", type=int, default=40)
     ap.add_argument("--cpu-M", type=int, default=64, help="cube size of the CPU-baseline sample (0 = skip); 64 = 1.57M tets, ~10-15 s of CPU work")
