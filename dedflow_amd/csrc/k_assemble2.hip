@@ -4,10 +4,10 @@
 //                         once per tet touching the patch, everything the sixteen (a,b) blocks of that tet share
 //                         (shape gradients, |det J|, convective shape derivatives and stabilisation parameters at the four
 //                         quadrature points; src/assemble.cu:528-603) into an LDS record.  Phase 2 gives every nodal
-//                         nonzero ("slot") of the owned rows to one lane quad: each lane walks a quarter of the slot's
-//                         (tet, a, b) contribution list (host/slotpatch.c), evaluates those blocks (assemble.cu:618-661)
-//                         from the LDS records and adds them up in registers; one DPP reduce-scatter inside the quad,
-//                         then the 128-byte block line is written ONCE (val = beta * val + sum).
+//                         nonzero ("slot") of the owned rows to one lane PAIR: each lane walks every other entry of the
+//                         slot's (tet, a, b) contribution list (host/slotpatch.c), evaluates those blocks
+//                         (assemble.cu:618-661) from the LDS records and adds them up in registers; one DPP exchange
+//                         inside the pair, then the 128-byte block line is written ONCE (val = beta * val + sum).
 //                         No atomics anywhere, fixed summation order => bitwise reproducible like the reference's colored
 //                         scatter (matrix_impl.cu:370-453), at one launch instead of one per color.
 //
@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int SBLK = 256;
+constexpr int SBLK = DFL_SLOT_BLOCK;
 constexpr int SP_RS = 34;  // doubles per LDS tet record: shg[12] conv[a][q] (16) tauM[4] sum tauC, detJ
 
 typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
@@ -89,12 +89,13 @@ __device__ __forceinline__ void slot_tet_record(const double2* r, double* rec) {
     rec[33] = detJ;
 }
 
-// PROBE = true only under dfl_tune_asm (developer phase split: bit 0 skip phase 2, bit 1 skip phase 1, bit 2 skip the
-// block evaluation, bit 3 skip the store); the shipped instantiation carries no probe branches
+// PROBE != 0 only under dfl_tune_asm (developer phase split: bit 0 skip phase 2, bit 1 skip phase 1, bit 2 skip the
+// block evaluation, bit 3 skip the store, 32 every lane reads tet record 0 = no LDS bank conflicts); the shipped
+// instantiation carries no probe branches
 // EARLY: the node records of the next patch are requested before phase 2 (they fly during it, at the price of 48 more
 // live registers: 2 waves per SIMD); otherwise after it (their latency is covered by the other resident workgroups)
-template <bool BETA0, bool PROBE, bool EARLY>
-__global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, const int4* __restrict__ hdr, const int4* __restrict__ ptet_ien,
+template <bool BETA0, int PROBE, bool EARLY>
+__global__ __launch_bounds__(SBLK, EARLY ? 2 : (SBLK == 512 ? 4 : 3)) void tet_lhs_slot_kernel(I P, const int4* __restrict__ hdr, const int4* __restrict__ ptet_ien,
                                                            const I* __restrict__ slot_nz, const I* __restrict__ coff,
                                                            const unsigned short* __restrict__ desc,
                                                            const T* __restrict__ nodep, T* __restrict__ val, T beta,
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, 
         const uint2 n_d0 = srcn[max(0, min(t, nqn - 1))];
         const uint2 n_d1 = srcn[max(0, min(t + SBLK, nqn - 1))];
         // (b) phase 1: one lane per (patch, tet); the records were requested one patch ago
-        if (t < nt && !(dbg & 2)) {
+        if (t < nt && !((PROBE & 2) && (dbg & 2))) {
             if (!EARLY) slot_load_records(nodep, nd, r);
             slot_tet_record(r, s_tet + t * SP_RS);
         }
@@ -179,26 +180,27 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, 
         // hop 3 for the next patch (EARLY only): its node records fly during phase 2
         if (EARLY && has_next && t < hn.y) slot_load_records(nodep, ndn, r);
 
-        // ---- phase 2: one lane quad per slot ---------------------------------------------------------------------
-        if (!(dbg & 1)) {
+        // ---- phase 2: one lane pair per slot ---------------------------------------------------------------------
+        if (!((PROBE & 1) && (dbg & 1))) {
             const int* s_coff = reinterpret_cast<const int*>(s_lists + buf * lbytes);
             const int* s_nz = s_coff + max_slots + 1;
             const unsigned short* s_desc = reinterpret_cast<const unsigned short*>(s_lists + buf * lbytes + desc_off);
-            const int j = t & 3;
-            const bool hi2 = (j >> 1) != 0, hi1 = (j & 1) != 0;
-            for (int sq = t >> 2; sq < ns; sq += SBLK / 4) {
+            const int j = t & 1;
+            const bool hi1 = j != 0;
+            for (int sq = t >> 1; sq < ns; sq += SBLK / 2) {
                 const int cb0 = s_coff[sq], cb1 = s_coff[sq + 1];
-                const int nzr = s_nz[sq];  // bit 30: first quad of a split slot, bit 31: one of its other three quads
+                const int nzr = s_nz[sq];  // bit 30: first pair of a split slot, bit 31: one of its other three pairs
                 const long long nz = nzr & 0x3fffffff;
                 double acc[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.0;
                 int c = cb0 + j;
-                int d = c < cb1 ? s_desc[c] : 0;
                 while (c < cb1) {
-                    const int dn = c + 4 < cb1 ? s_desc[c + 4] : 0;  // the next descriptor is fetched before this one is used
+                    // (fetching the next descriptor one trip ahead was tried both ways: the conditional read makes the wait
+                    // for the current one an lgkmcnt(0), the unconditional clamped read is rotated back into this form)
+                    const int d = s_desc[c];
                     const int aa = (d >> 2) & 3, bb = d & 3;
-                    const double* rec = s_tet + (d >> 4) * SP_RS;
+                    const double* rec = s_tet + (((PROBE & 4) && (dbg & 32)) ? 0 : (d >> 4)) * SP_RS;  // probe 32: no bank conflicts
                     double ga[3], gb[3], t0q[4], ca[4], cb[4];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
@@ -212,47 +214,45 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 3) void tet_lhs_slot_kernel(I P, 
                     ca[0] = ca01.x; ca[1] = ca01.y; ca[2] = ca23.x; ca[3] = ca23.y;
                     cb[0] = cb01.x; cb[1] = cb01.y; cb[2] = cb23.x; cb[3] = cb23.y;
                     t0q[0] = ta01.x; t0q[1] = ta01.y; t0q[2] = ta23.x; t0q[3] = ta23.y;
-                    if (PROBE && (dbg & 4)) {
+                    if ((PROBE & 4) && (dbg & 4)) {
                         acc[0] += ga[0] + gb[1] + ca[2] + cb[3] + t0q[0] + sc.x + sc.y + cb_a + ca_b + t0_b;
                     } else {
                         lhs_block_accumulate(aa == bb, ga, gb, sc.y, t0q, sc.x, ca, cb, cb_a, ca_b, t0_b, acc);
                     }
-                    d = dn;
-                    c += 4;
+                    c += 2;
                 }
-                // reduce-scatter inside the quad: lane j ends up with entries {2j, 2j+1, 8+2j, 9+2j} summed over the 4 lanes
-                double r8[8];
+                // reduce-scatter inside the pair: lane j ends up with the 16-byte pieces {j, j + 2, j + 4, j + 6} of the
+                // 128-byte line (entries 4k + 2j, 4k + 2j + 1) summed over both lanes, so that every store instruction
+                // of a pair covers one contiguous 32-byte sector
+                double2 e[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    r8[i] = (hi2 ? acc[i + 4] : acc[i]) + dpp_quad<0x4E>(hi2 ? acc[i] : acc[i + 4]);
-                    r8[4 + i] = (hi2 ? acc[i + 12] : acc[i + 8]) + dpp_quad<0x4E>(hi2 ? acc[i + 8] : acc[i + 12]);
+                for (int k = 0; k < 4; ++k) {
+                    e[k].x = (hi1 ? acc[4 * k + 2] : acc[4 * k]) + dpp_quad<0xB1>(hi1 ? acc[4 * k] : acc[4 * k + 2]);
+                    e[k].y = (hi1 ? acc[4 * k + 3] : acc[4 * k + 1]) + dpp_quad<0xB1>(hi1 ? acc[4 * k + 1] : acc[4 * k + 3]);
                 }
-                double2 e0, e1;
-                e0.x = (hi1 ? r8[2] : r8[0]) + dpp_quad<0xB1>(hi1 ? r8[0] : r8[2]);
-                e0.y = (hi1 ? r8[3] : r8[1]) + dpp_quad<0xB1>(hi1 ? r8[1] : r8[3]);
-                e1.x = (hi1 ? r8[6] : r8[4]) + dpp_quad<0xB1>(hi1 ? r8[4] : r8[6]);
-                e1.y = (hi1 ? r8[7] : r8[5]) + dpp_quad<0xB1>(hi1 ? r8[5] : r8[7]);
                 if (nzr & 0xC0000000) {
-                    // split slot (host/slotpatch.c): its four parts sit in the four quads of this 16-lane DPP row; lane j of
-                    // the first quad collects lane j of the others: (q0 + q1) + (q2 + q3), two row shifts
-                    e0.x += dpp_quad<0x104>(e0.x); e0.y += dpp_quad<0x104>(e0.y);
-                    e1.x += dpp_quad<0x104>(e1.x); e1.y += dpp_quad<0x104>(e1.y);
-                    e0.x += dpp_quad<0x108>(e0.x); e0.y += dpp_quad<0x108>(e0.y);
-                    e1.x += dpp_quad<0x108>(e1.x); e1.y += dpp_quad<0x108>(e1.y);
-                    if (nzr < 0) continue;  // only the first quad stores
+                    // split slot (host/slotpatch.c): its four parts sit in four adjacent pairs (half a 16-lane DPP row, aligned);
+                    // lane j of the first pair collects lane j of the others: (p0 + p1) + (p2 + p3), two row shifts
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { e[k].x += dpp_quad<0x102>(e[k].x); e[k].y += dpp_quad<0x102>(e[k].y); }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { e[k].x += dpp_quad<0x104>(e[k].x); e[k].y += dpp_quad<0x104>(e[k].y); }
+                    if (nzr < 0) continue;  // only the first pair stores
                 }
-                if (PROBE && (dbg & 8)) {
-                    if (e0.x == 1.2345e300) val[nz] = e0.x + e0.y + e1.x + e1.y;
+                if ((PROBE & 8) && (dbg & 8)) {
+                    if (e[0].x == 1.2345e300) val[nz] = e[0].x + e[0].y + e[1].x + e[1].y + e[2].x + e[2].y + e[3].x + e[3].y;
                     continue;
                 }
                 double2* dst = reinterpret_cast<double2*>(val + nz * 16) + j;
                 if (!BETA0) {
-                    const double2 o0 = dst[0], o1 = dst[4];
-                    e0.x += beta * o0.x; e0.y += beta * o0.y;
-                    e1.x += beta * o1.x; e1.y += beta * o1.y;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double2 o = dst[2 * k];
+                        e[k].x += beta * o.x; e[k].y += beta * o.y;
+                    }
                 }
-                dst[0] = e0;
-                dst[4] = e1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[2 * k] = e[k];
             }
         }
         if (!has_next) break;
@@ -682,36 +682,37 @@ void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const I* ptet_ien, 
     static size_t lds_set = 0;
     static int resident = 0, resident_early = 0;
     if (lds != lds_set) {
-        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DFL_GUARD(hipFuncSetAttribute((const void*)tet_lhs_slot_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const void* kernels[6] = {(const void*)tet_lhs_slot_kernel<true, 0, true>,  (const void*)tet_lhs_slot_kernel<false, 0, true>,
+                                  (const void*)tet_lhs_slot_kernel<true, 0, false>, (const void*)tet_lhs_slot_kernel<false, 0, false>,
+                                  (const void*)tet_lhs_slot_kernel<true, 15, true>, (const void*)tet_lhs_slot_kernel<true, 15, false>};
+        for (int k = 0; k < 6; ++k) DFL_GUARD(hipFuncSetAttribute(kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0, cus = 0, occ = 0;
         DFL_GUARD(hipGetDevice(&dev));
         DFL_GUARD(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        DFL_GUARD(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)tet_lhs_slot_kernel<true, false, false>, SBLK, lds));
-        if (occ < 1) occ = 1;
         if (cus < 8) cus = 8;
-        resident = cus * occ;
-        DFL_GUARD(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)tet_lhs_slot_kernel<true, true, true>, SBLK, lds));
+        DFL_GUARD(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernels[2], SBLK, lds));
+        resident = cus * (occ < 1 ? 1 : occ);
+        DFL_GUARD(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernels[0], SBLK, lds));
         resident_early = cus * (occ < 1 ? 1 : occ);
         lds_set = lds;
     }
-    int grid = resident / 8 * 8;
+    // default: the late build; dfl_tune_asm bit 16 = EARLY (node records of the next patch requested before phase 2)
+    const bool early = (g_patch_dbg & 16) != 0;
+    const int probe = g_patch_dbg & ~16;  // any other bit: the probe build (always overwrites: beta = 0)
+    int grid = (early ? resident_early : resident) / 8 * 8;
     const int need = 8 * ((npatch + 7) / 8);
     if (grid > need) grid = need;
     const int4* h4 = reinterpret_cast<const int4*>(hdr);
     const int4* pi4 = reinterpret_cast<const int4*>(ptet_ien);
-    if (g_patch_dbg & 16) {  // developer A/B: early record prefetch (2 waves per SIMD), grid for that occupancy
-        int g2 = resident_early / 8 * 8;
-        if (g2 > need) g2 = need;
-        tet_lhs_slot_kernel<true, true, true><<<g2, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, max_contrib, g_patch_dbg);
-    } else if (g_patch_dbg)
-        tet_lhs_slot_kernel<true, true, false><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, max_contrib, g_patch_dbg);
-    else if (beta == 0.0)
-        tet_lhs_slot_kernel<true, false, false><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, max_contrib, 0);
-    else
-        tet_lhs_slot_kernel<false, false, false><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, max_contrib, 0);
+#define SLOT_LAUNCH(B0, PR, EA) tet_lhs_slot_kernel<B0, PR, EA><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, max_contrib, probe)
+    if (probe) {
+        if (early) SLOT_LAUNCH(true, 15, true); else SLOT_LAUNCH(true, 15, false);
+    } else if (beta == 0.0) {
+        if (early) SLOT_LAUNCH(true, 0, true); else SLOT_LAUNCH(true, 0, false);
+    } else {
+        if (early) SLOT_LAUNCH(false, 0, true); else SLOT_LAUNCH(false, 0, false);
+    }
+#undef SLOT_LAUNCH
     DFL_LAUNCH_CHECK();
 }
 

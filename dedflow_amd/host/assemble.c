@@ -29,8 +29,8 @@ void DflSetRowPatchParameters(index_type leaf_nodes, index_type slot_cap) {
 }
 void DflSetSlotPatchParameters(index_type leaf_nodes, index_type slot_cap, index_type tet_cap) {
     if (leaf_nodes > 0) g_asm.slot_leaf = leaf_nodes;
-    if (slot_cap > 0) g_asm.slot_cap = slot_cap > 255 ? 255 : slot_cap;
-    if (tet_cap > 0) g_asm.slot_tets = tet_cap > 256 ? 256 : tet_cap;
+    if (slot_cap > 0) g_asm.slot_cap = slot_cap > DFL_SLOT_BLOCK - 1 ? DFL_SLOT_BLOCK - 1 : slot_cap;
+    if (tet_cap > 0) g_asm.slot_tets = tet_cap > DFL_SLOT_BLOCK ? DFL_SLOT_BLOCK : tet_cap;
 }
 void DflSetRhsPatchParameters(index_type leaf_tets, index_type node_cap) {
     if (leaf_tets > 0 && leaf_tets <= dfl_rhs_patch_max_tets()) g_asm.rhspatch_leaf = leaf_tets;

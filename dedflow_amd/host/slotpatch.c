@@ -6,9 +6,10 @@
  * nodal nonzero ("slot") is formed in REGISTERS by the lane group that owns the slot:
  *   phase 1  one lane per tet touching the patch: geometry, convective shape derivatives and stabilisation
  *            parameters at the 4 quadrature points -> a 304-byte record in LDS;
- *   phase 2  one lane quad per slot walks the slot's list of (tet, a, b) contributions (this file builds it),
- *            evaluates the (a, b) block of each from the LDS records, adds them in list order and writes the
- *            128-byte line once.
+ *   phase 2  one lane PAIR per slot walks the slot's list of (tet, a, b) contributions (this file builds it), each lane
+ *            every other entry: evaluates the (a, b) block of each from the LDS records, adds them in list order, the
+ *            two lanes exchange halves and write the 128-byte line once.  (Lane quads were the first form: with 4-6
+ *            contributions per edge slot a quad idles a quarter of its lanes on the second trip; pairs: 2.31 -> 2.06 ms.)
  * No LDS or HBM atomics, one launch, fixed summation order (bitwise reproducible), no per-element geometry cache
  * (geometry is recomputed from the node records, so moving meshes need no invalidation).
  *
@@ -16,8 +17,8 @@
  *   hdr[p]      = {tet_off, num_tet, slot_off, num_slot, contrib_off, num_contrib, 0, 0}
  *   ptet_ien    [sum num_tet][4]  node ids of every (patch, tet) pair, ascending element id inside a patch
  *   slot_nz     [nnz1]            nodal nonzero of every slot; inside a patch the slots are sorted by contribution
- *                                 count (descending) and dealt to the four waves in snake order, so that the 16 lane
- *                                 quads of a wave see equal trip counts
+ *                                 count (descending) and dealt to the waves in snake order, so that the 32 lane
+ *                                 pairs of a wave see equal trip counts
  *   coff        [nnz1 + 1]        contribution offsets in slot order
  *   desc        [16 T]            (local tet << 4) | (a << 2) | b, ascending local tet inside a slot
  */
@@ -28,9 +29,9 @@
 #include "host_private.h"
 #include "rcb.h"
 
-#define SPLIT_MIN 12              /* contributions from which a (diagonal) slot is cut into four quads */
-#define SLOT_LEADER 0x40000000    /* slot_nz flag: first quad of a split slot (sums the four quads, stores the line) */
-#define SLOT_FOLLOWER 0x80000000u /* slot_nz flag: quads 2-4 of a split slot (no store) */
+#define SPLIT_MIN 12              /* contributions from which a (diagonal) slot is cut into four parts (one lane pair each) */
+#define SLOT_LEADER 0x40000000    /* slot_nz flag: first pair of a split slot (sums the four parts, stores the line) */
+#define SLOT_FOLLOWER 0x80000000u /* slot_nz flag: pairs 2-4 of a split slot (no store) */
 
 typedef struct { index_type lo, hi; } Range;
 typedef struct {
@@ -86,10 +87,10 @@ static void split(Ctx* x, index_type lo, index_type hi) {
     if (n <= x->leaf) {
         int64_t slots = 0;
         for (index_type i = lo; i < hi; ++i) slots += x->rp[x->idx[i] + 1] - x->rp[x->idx[i]];
-        int64_t items = 0; /* (tet, owned node) pairs: 4 contributions each, at most 2048 per patch (8 per lane) */
+        int64_t items = 0; /* (tet, owned node) pairs: 4 contributions each, at most 8 per lane of the workgroup */
         for (index_type i = lo; i < hi; ++i) items += x->vp[x->idx[i] + 1] - x->vp[x->idx[i]];
-        /* + 3 positions per node: a diagonal slot (>= SPLIT_MIN contributions) is walked by four quads */
-        if (n <= 1 || (slots + 3 * (int64_t)n <= x->cap && items <= 512 && count_tets(x, lo, hi) <= x->tcap)) { emit(x, lo, hi); return; }
+        /* + 3 positions per node: a diagonal slot (>= SPLIT_MIN contributions) is walked by four lane pairs */
+        if (n <= 1 || (slots + 3 * (int64_t)n <= x->cap && items <= 2 * DFL_SLOT_BLOCK && count_tets(x, lo, hi) <= x->tcap)) { emit(x, lo, hi); return; }
     }
     f64 bl[3] = {1e300, 1e300, 1e300}, bh[3] = {-1e300, -1e300, -1e300};
     for (index_type i = lo; i < hi; ++i)
@@ -130,8 +131,8 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     const index_type* ien = mesh->host->ien;
     const f64* xg = mesh->host->xg;
     ASSERT((int64_t)T * 16 < 2147483647LL && "slot-patch contribution offsets are 32-bit");
-    if (tet_cap > 256) tet_cap = 256;   /* one tet per lane in phase 1 (and 12-bit local tet ids in the descriptors) */
-    if (slot_cap > 255) slot_cap = 255; /* one slot offset per lane */
+    if (tet_cap > DFL_SLOT_BLOCK) tet_cap = DFL_SLOT_BLOCK;       /* one tet per lane in phase 1 (and 12-bit local tet ids in the descriptors) */
+    if (slot_cap > DFL_SLOT_BLOCK - 1) slot_cap = DFL_SLOT_BLOCK - 1; /* one slot offset per lane */
     SlotPatchSched* ps = (SlotPatchSched*)CdamMallocHost(SIZE_OF(SlotPatchSched));
     memset(ps, 0, sizeof *ps);
     ps->attr = spy;
@@ -198,7 +199,7 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
             ns += rp[idx[i] + 1] - rp[idx[i]];
             if (vp[idx[i] + 1] - vp[idx[i]] >= SPLIT_MIN) ns += 3;
         }
-        ASSERT(ns <= 255 || x.out[p].hi - x.out[p].lo == 1);
+        ASSERT(ns <= DFL_SLOT_BLOCK - 1 || x.out[p].hi - x.out[p].lo == 1);
         ASSERT(nt_of[p] <= 4095 && "slot-patch descriptors hold 12-bit local tet ids");
         hdr[8 * p + 0] = (int32_t)tot_t;
         hdr[8 * p + 1] = nt_of[p];
@@ -276,11 +277,11 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
             }
         }
         /* Positions.  A diagonal slot (>= SPLIT_MIN contributions; 24 in the interior of a Kuhn mesh against 4-6 for an
-           edge slot) is cut into four consecutive parts, each walked by its own quad -- four adjacent quads = one 16-lane
-           DPP row, summed by two row shifts in the kernel -- so that every quad of a wave pass has 1-2 trips instead of
-           the whole pass waiting 6 trips for its diagonal slots.  Ranks: the split slots first (4 ranks each, descending
-           count), then the others by descending count; ranks are dealt to the four waves in snake order in chunks of 16
-           quads (a multiple of 4: the groups stay aligned). */
+           edge slot) is cut into four consecutive parts, each walked by its own lane pair -- four adjacent pairs = half a
+           16-lane DPP row, summed by two row shifts in the kernel -- so that every pair of a wave pass has 2-3 trips
+           instead of the whole pass waiting 12 trips for its diagonal slots.  Ranks: the split slots first (4 ranks each,
+           descending count), then the others by descending count; ranks are dealt to the waves in snake order in chunks
+           of 32 pairs (a multiple of 4: the groups stay aligned). */
         const index_type np = hdr[8 * p + 3];
         index_type* first_rank = (index_type*)malloc(sizeof(index_type) * (size_t)(ns > 0 ? ns : 1));
         unsigned char* is_split = (unsigned char*)calloc((size_t)(ns > 0 ? ns : 1), 1);
@@ -305,8 +306,9 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
         ASSERT(np == ns + 3 * nsplit);
         for (index_type s = 0; s < ns; ++s)
             first_rank[s] = is_split[s] ? 4 * bsplit[maxc - cnt[s]]++ : 4 * nsplit + bsingle[maxc - cnt[s]]++;
-        const index_type full = (np / 64) * 64;
-#define RANK_TO_POS(r) ((r) < full ? (((r) >> 6) * 64 + (((((r) >> 6) & 1) ? 3 - (((r) >> 4) & 3) : (((r) >> 4) & 3)) * 16) + ((r) & 15)) : (r))
+        const index_type pass = DFL_SLOT_BLOCK / 2, nwave = DFL_SLOT_BLOCK / 64; /* lane pairs per pass over the positions; waves */
+        const index_type full = (np / pass) * pass;
+#define RANK_TO_POS(r) ((r) < full ? (((r) / pass) * pass + (((((r) / pass) & 1) ? nwave - 1 - (((r) % pass) >> 5) : (((r) % pass) >> 5)) * 32) + ((r) & 31)) : (r))
         /* contribution counts in position order, then offsets */
         index_type* cpos = (index_type*)calloc((size_t)np + 1, sizeof(index_type));
         for (index_type s = 0; s < ns; ++s) {

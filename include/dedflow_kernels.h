@@ -342,6 +342,10 @@ void dfl_assemble_tet_lhs_rowpatch(dfl_index npatch, const dfl_index* p_ioff, co
  * val = beta * val + assembled rows (beta = 0 overwrites).  max_tets / max_slots / max_contrib = largest num_tet /
  * num_slot / num_contrib over the patches (they size the workgroup's LDS: dfl_lhs_slot_lds_bytes).  No atomics:
  * bitwise reproducible. */
+#ifndef DFL_SLOT_BLOCK
+#define DFL_SLOT_BLOCK 256 /* threads of a slot-owner workgroup: caps a patch at this many tets, DFL_SLOT_BLOCK - 1 slot
+                              positions and 8 * DFL_SLOT_BLOCK contributions (host/slotpatch.c builds to these caps) */
+#endif
 int dfl_lhs_slot_record_bytes(void);
 int64_t dfl_lhs_slot_lds_bytes(dfl_index max_tets, dfl_index max_slots, dfl_index max_contrib);
 void dfl_assemble_tet_lhs_slot(dfl_index npatch, const int32_t* hdr, const dfl_index* ptet_ien, const dfl_index* slot_nz,

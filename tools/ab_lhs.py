@@ -1,5 +1,7 @@
 """A/B of the Jacobian-assembly schedules (1 = compact colors, 2 = tet patches, 3 = row-owner node patches, 4 = slot-owner
-node patches) at M (default 119); extra args are mode:leaf:cap[:tetcap] tuples."""
+node patches) at M (default 119); extra args are mode:leaf:cap[:tetcap] tuples.  AB_OVERWRITE=1 times the
+overwrite form AssembleSystem uses for schedules 3 and 4 (val = assembled rows: no MatrixZero, no read of the old values)
+instead of MatrixZero + accumulate; the first config (schedule 1) is then skipped."""
 import ctypes as C, sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +16,11 @@ configs = [(1, 0, 0, 0)] + [parse(c) for c in sys.argv[2:]] if len(sys.argv) > 2
 mesh = kuhn_cube(M, jitter=0.2)
 wg, dwg = synthetic_fields(mesh)
 L = api.lib()
+OVERWRITE = os.environ.get("AB_OVERWRITE") == "1"
+if OVERWRITE:
+    L.DflAssembleSystemTetBeta.restype = None
+    L.DflAssembleSystemTetBeta.argtypes = [C.POINTER(api.Mesh3D), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(api.Matrix), C.c_double]
+    configs = [c for c in configs if c[0] >= 3]
 ref = None
 for mode, leaf, cap, tcap in configs:
     if mode == 2:
@@ -31,11 +38,15 @@ for mode, leaf, cap, tcap in configs:
     t_setup = time.perf_counter() - t0
     t = api.Timer()
     res = []
-    for rep in range(5):
-        L.MatrixZero(P.J)
+    for rep in range(9 if OVERWRITE else 5):
+        if not OVERWRITE:
+            L.MatrixZero(P.J)
         api.sync()
         t.start()
-        P.assemble_tet(wg_d, dwg_d, None, want_J=True)
+        if OVERWRITE:
+            L.DflAssembleSystemTetBeta(P.mesh, wg_d.ptr, dwg_d.ptr, None, P.J, 0.0)
+        else:
+            P.assemble_tet(wg_d, dwg_d, None, want_J=True)
         t.stop()
         res.append(t.ms())
     L.MatrixZero(P.J)

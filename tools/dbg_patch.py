@@ -1,4 +1,7 @@
-"""Developer probe: time split of the patch LHS kernel (dfl_tune_asm bits: 1 skip element loop, 2 skip flush, 4 skip LDS atomics (mode 2), 8 write-only flush (mode 3))."""
+"""Developer probe: time split of the patch LHS kernel (dfl_tune_asm bits: 1 skip element loop, 2 skip flush, 4 skip LDS atomics (mode 2), 8 write-only flush (mode 3)).
+Schedule 4 (slot owner): 1 skip phase 2, 2 skip phase 1, 4 skip the block evaluation, 8 skip the store, 16 EARLY build, 32 every lane reads
+tet record 0 (no LDS bank conflicts); any bit but 16 selects the probe build, which always overwrites (256 = probe build, nothing skipped).
+Usage: dbg_patch.py M mode:leaf:cap[:tetcap] [comma-separated dfl_tune_asm values]"""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +23,7 @@ L.MatrixZero(P.J)
 P.assemble_tet(wg_d, dwg_d, None, want_J=True)
 api.sync()
 REPS = int(os.environ.get('DFL_DBG_REPS', 20))
-seq = (0,) if len(sys.argv) > 3 else ((0, 16, 1, 2, 4, 6, 8, 24, 0) if mode == 4 else (0, 8, 2, 10, 1, 3, 0))
+seq = tuple(int(v) for v in sys.argv[3].split(',')) if len(sys.argv) > 3 else ((256, 272, 257, 258, 259, 260, 262, 264, 268, 288, 256) if mode == 4 else (0, 8, 2, 10, 1, 3, 0))
 for dbg in seq:
     L.dfl_tune_asm(dbg)
     for rep in range(3):
