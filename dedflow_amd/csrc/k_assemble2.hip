@@ -23,17 +23,21 @@ constexpr int SP_RS = 34;  // doubles per LDS tet record: shg[12] conv[a][q] (16
 
 typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
 
-// Dynamic LDS of one workgroup: [max_tets] tet records | 2 x { [max_slots + 1] contribution offsets (relative to the
-// patch) | [max_slots] nodal nonzero of each slot | [max_contrib] contribution descriptors }.  The workgroups are
-// PERSISTENT (grid = resident workgroups; each walks its share of the patches) and software-pipelined: while phase 2 of
-// patch p runs, the node records of the next patch are in flight into registers and its three lists sit in registers
-// waiting for the second list buffer, so neither phase 1 nor phase 2 waits on HBM and the row stores of patch p drain
-// behind the work on patch p+1.
-__host__ __device__ inline size_t slot_list_bytes(int max_slots, int max_contrib) {
-    return (size_t)(((2 * max_slots + 1) * 4 + 15) & ~15) + (size_t)((max_contrib * 2 + 15) & ~15);
-}
-__host__ __device__ inline size_t slot_lds_bytes(int max_tets, int max_slots, int max_contrib) {
-    return (size_t)max_tets * SP_RS * 8 + 2 * slot_list_bytes(max_slots, max_contrib);
+// Dynamic LDS of one workgroup: [max_tets] tet records, nothing else.  The workgroups are PERSISTENT (grid = resident
+// workgroups; each walks its share of the patches) and software-pipelined: the slot map and the lane-major contribution
+// descriptors of the NEXT patch (host/slotpatch.c) are requested into registers before phase 1 of this one and have arrived
+// before its row stores are issued, so neither phase waits on HBM and the row stores of patch p drain behind the work on
+// patch p+1.  (The first form staged offset / slot / descriptor lists in a double LDS buffer: three dependent LDS round trips
+// per slot before the first block evaluation and 45 KB of LDS per workgroup = 3 workgroups per CU; now 34 KB = 4.)
+__host__ __device__ inline size_t slot_lds_bytes(int max_tets) { return (size_t)max_tets * SP_RS * 8; }
+
+// first descriptor group of (pass, wave w) inside the patch: groups are stored pass-major, wave by wave, ceil(trips / 2) per
+// (pass, wave); trips: one byte per (pass, wave) in lo (pass 0) / hi (pass 1), at most 254
+__device__ __forceinline__ int slot_byte_sum(unsigned x) { return (int)((x & 255u) + ((x >> 8) & 255u) + ((x >> 16) & 255u) + (x >> 24)); }
+__device__ __forceinline__ int slot_first_group(unsigned lo, unsigned hi, int pass, int w) {
+    const unsigned glo = ((lo + 0x01010101u) >> 1) & 0x7f7f7f7fu, ghi = ((hi + 0x01010101u) >> 1) & 0x7f7f7f7fu;  // groups per byte
+    const unsigned below = (1u << (8 * w)) - 1u;  // w = 0..3
+    return pass ? slot_byte_sum(glo) + slot_byte_sum(ghi & below) : slot_byte_sum(glo & below);
 }
 
 __device__ __forceinline__ void slot_load_records(const T* __restrict__ nodep, const int4& nd, double2* r) {
@@ -95,16 +99,12 @@ __device__ __forceinline__ void slot_tet_record(const double2* r, double* rec) {
 // EARLY: the node records of the next patch are requested before phase 2 (they fly during it, at the price of 48 more
 // live registers: 2 waves per SIMD); otherwise after it (their latency is covered by the other resident workgroups)
 template <bool BETA0, int PROBE, bool EARLY>
-__global__ __launch_bounds__(SBLK, EARLY ? 2 : (SBLK == 512 ? 4 : 3)) void tet_lhs_slot_kernel(I P, const int4* __restrict__ hdr, const int4* __restrict__ ptet_ien,
-                                                           const I* __restrict__ slot_nz, const I* __restrict__ coff,
-                                                           const unsigned short* __restrict__ desc,
-                                                           const T* __restrict__ nodep, T* __restrict__ val, T beta,
-                                                           int max_tets, int max_slots, int max_contrib, int dbg_in) {
+__global__ __launch_bounds__(SBLK, EARLY ? 2 : 4) void tet_lhs_slot_kernel(I P, const int4* __restrict__ hdr, const int4* __restrict__ ptet_ien,
+                                                           const I* __restrict__ slot_nz, const unsigned* __restrict__ ldesc,
+                                                           const T* __restrict__ nodep, T* __restrict__ val, T beta, int max_tets, int dbg_in) {
+    static_assert(SBLK == 256, "trip bytes: four waves x two passes");
     const int dbg = PROBE ? dbg_in : 0;
     extern __shared__ __attribute__((aligned(16))) double s_tet[];
-    char* const s_lists = reinterpret_cast<char*>(s_tet + (size_t)max_tets * SP_RS);
-    const int lbytes = (int)slot_list_bytes(max_slots, max_contrib);
-    const int desc_off = ((2 * max_slots + 1) * 4 + 15) & ~15;
     // XCD-aware order: workgroup w runs on XCD w % 8; every XCD gets one contiguous range of the spatially ordered
     // patches (neighbouring patches share tets and node records -> one L2), dealt round-robin to its workgroups
     const int per = (P + 7) >> 3;
@@ -114,18 +114,22 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : (SBLK == 512 ? 4 : 3)) void tet_l
     int p = pbeg + (blockIdx.x >> 3);
     if (p >= pend) return;
     const int t = threadIdx.x;
+    const int lane = t & 63, pr = t >> 1;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int4 zero4 = make_int4(0, 0, 0, 0);
 
-    // ---- prologue: lists of the first patch straight into buffer 0, its node records into registers -----------------
+    // ---- prologue: slot map and descriptors of the first patch, its connectivity ----------------------------------------
     int4 h = hdr[2 * p], h2 = hdr[2 * p + 1];
+    int nz0, nz1;
+    unsigned d0a, d0b, d1a, d1b;  // descriptor groups 0, 1 of pass 0 and of pass 1 (two trips each)
     {
-        int* lc = reinterpret_cast<int*>(s_lists);
-        int* lz = lc + max_slots + 1;
-        uint2* ld = reinterpret_cast<uint2*>(s_lists + desc_off);
-        if (t <= h.w) lc[t] = coff[h.z + t] - h2.x;
-        if (t < h.w) lz[t] = slot_nz[h.z + t];
-        const uint2* src = reinterpret_cast<const uint2*>(desc + h2.x);  // h2.x is a multiple of 4 descriptors (8 bytes)
-        for (int k = t; k < (h2.y + 3) >> 2; k += SBLK) ld[k] = src[k];
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(h2.y), hi = (unsigned)__builtin_amdgcn_readfirstlane(h2.z);
+        const int g0 = slot_first_group(lo, hi, 0, w), g1 = slot_first_group(lo, hi, 1, w);
+        const unsigned* lp = ldesc + (long long)__builtin_amdgcn_readfirstlane(h2.x) * 64 + lane;
+        nz0 = slot_nz[h.z + max(0, min(pr, h.w - 1))];
+        nz1 = slot_nz[h.z + max(0, min(pr + SBLK / 2, h.w - 1))];
+        d0a = lp[g0 * 64]; d0b = lp[g0 * 64 + 64];
+        d1a = lp[g1 * 64]; d1b = lp[g1 * 64 + 64];
     }
     double2 r[12];
     int4 nd = zero4;
@@ -134,78 +138,76 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : (SBLK == 512 ? 4 : 3)) void tet_l
     int pn = p + g8;
     int4 hn = zero4, hn2 = zero4;
     if (pn < pend) { hn = hdr[2 * pn]; hn2 = hdr[2 * pn + 1]; }
-    int buf = 0;
-    // the first patch's connectivity has arrived before the loop is entered: inside the loop the same registers carry the
-    // next patch's (already waited for), and the compiler merges the two states -- without this it waits at the loop top for
+    // the first patch's lists have arrived before the loop is entered: inside the loop the same registers carry the next
+    // patch's (already waited for), and the compiler merges the two states -- without this it waits at the loop top for
     // everything older than the new list loads, i.e. for the previous patch's row stores
-    asm volatile("" ::"v"(nd.x), "v"(nd.y), "v"(nd.z), "v"(nd.w));
+    asm volatile("" ::"v"(nd.x), "v"(nd.y), "v"(nd.z), "v"(nd.w), "v"(nz0), "v"(nz1), "v"(d0a), "v"(d0b), "v"(d1a), "v"(d1b));
 
     for (;;) {
         const bool has_next = pn < pend;
-        const int nt = h.y, ns = h.w;
-        // (a) hop 2 for the next patch: connectivity of this lane's tet + the three lists, into registers.  Every load is
-        // unconditional (indices clamped into the patch; past the last patch the header is all zero and patch 0's first
+        const int nt = h.y;
+        const int np = __builtin_amdgcn_readfirstlane(h.w);
+        const unsigned tlo = (unsigned)__builtin_amdgcn_readfirstlane(h2.y), thi = (unsigned)__builtin_amdgcn_readfirstlane(h2.z);
+        // (a) hop 2 for the next patch: connectivity of this lane's tet, slot map and descriptors, into registers.  Every load
+        // is unconditional (indices clamped into the patch; past the last patch the header is all zero and patch 0's first
         // entries are read and dropped) and nothing is computed from the results here: the wave goes on to phase 1 with
-        // all of them in flight, and they are consumed right after phase 1 -- BEFORE this patch's row stores are issued,
+        // all of them in flight, and they are waited for right after phase 1 -- BEFORE this patch's row stores are issued,
         // so that waiting for them never waits for a store
         const int pnn = pn + g8;
         int4 hnn = zero4, hnn2 = zero4;
         if (has_next && pnn < pend) { hnn = hdr[2 * pnn]; hnn2 = hdr[2 * pnn + 1]; }
-        const int nqn = (hn2.y + 3) >> 2;
-        const uint2* srcn = reinterpret_cast<const uint2*>(desc + hn2.x);
+        const unsigned nlo = (unsigned)__builtin_amdgcn_readfirstlane(hn2.y), nhi = (unsigned)__builtin_amdgcn_readfirstlane(hn2.z);
+        const int gn0 = slot_first_group(nlo, nhi, 0, w), gn1 = slot_first_group(nlo, nhi, 1, w);
+        const unsigned* lpn = ldesc + (long long)__builtin_amdgcn_readfirstlane(hn2.x) * 64 + lane;
         const int4 ndn = ptet_ien[hn.x + max(0, min(t, hn.y - 1))];
-        const int n_c = coff[hn.z + min(t, hn.w)];
-        const int n_z = slot_nz[hn.z + max(0, min(t, hn.w - 1))];
-        const uint2 n_d0 = srcn[max(0, min(t, nqn - 1))];
-        const uint2 n_d1 = srcn[max(0, min(t + SBLK, nqn - 1))];
-        // (b) phase 1: one lane per (patch, tet); the records were requested one patch ago
+        const int nzn0 = slot_nz[hn.z + max(0, min(pr, hn.w - 1))];
+        const int nzn1 = slot_nz[hn.z + max(0, min(pr + SBLK / 2, hn.w - 1))];
+        const unsigned dn0a = lpn[gn0 * 64], dn0b = lpn[gn0 * 64 + 64];
+        const unsigned dn1a = lpn[gn1 * 64], dn1b = lpn[gn1 * 64 + 64];
+        // (b) phase 1: one lane per (patch, tet)
         if (t < nt && !((PROBE & 2) && (dbg & 2))) {
             if (!EARLY) slot_load_records(nodep, nd, r);
             slot_tet_record(r, s_tet + t * SP_RS);
         }
         __syncthreads();
-        // (c) the lists of the next patch go into the other buffer (nobody reads it any more: the previous patch's phase 2
-        // ended before the barrier that closed the last trip; it is read after the barrier that follows the next phase 1)
-        if (has_next) {
-            char* nb = s_lists + (buf ^ 1) * lbytes;
-            int* lc = reinterpret_cast<int*>(nb);
-            int* lz = lc + max_slots + 1;
-            uint2* ld = reinterpret_cast<uint2*>(nb + desc_off);
-            if (t <= hn.w) lc[t] = n_c - hn2.x;
-            if (t < hn.w) lz[t] = n_z;
-            if (t < nqn) ld[t] = n_d0;
-            if (t + SBLK < nqn) ld[t + SBLK] = n_d1;
-        }
-        asm volatile("" ::"v"(ndn.x), "v"(ndn.y), "v"(ndn.z), "v"(ndn.w));  // the connectivity has arrived, too
+        // (c) everything requested for the next patch has arrived
+        asm volatile("" ::"v"(ndn.x), "v"(ndn.y), "v"(ndn.z), "v"(ndn.w), "v"(nzn0), "v"(nzn1), "v"(dn0a), "v"(dn0b), "v"(dn1a), "v"(dn1b));
         // hop 3 for the next patch (EARLY only): its node records fly during phase 2
         if (EARLY && has_next && t < hn.y) slot_load_records(nodep, ndn, r);
 
-        // ---- phase 2: one lane pair per slot ---------------------------------------------------------------------
+        // ---- phase 2: one lane pair per slot position, two passes over the positions ---------------------------------------
         if (!((PROBE & 1) && (dbg & 1))) {
-            const int* s_coff = reinterpret_cast<const int*>(s_lists + buf * lbytes);
-            const int* s_nz = s_coff + max_slots + 1;
-            const unsigned short* s_desc = reinterpret_cast<const unsigned short*>(s_lists + buf * lbytes + desc_off);
             const int j = t & 1;
             const bool hi1 = j != 0;
-            for (int sq = t >> 1; sq < ns; sq += SBLK / 2) {
-                const int cb0 = s_coff[sq], cb1 = s_coff[sq + 1];
-                const int nzr = s_nz[sq];  // bit 30: first pair of a split slot, bit 31: one of its other three pairs
+            const int g0 = slot_first_group(tlo, thi, 0, w), g1 = slot_first_group(tlo, thi, 1, w);
+            const unsigned* lp = ldesc + (long long)__builtin_amdgcn_readfirstlane(h2.x) * 64 + lane;
+#pragma nounroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int trips = (int)(((pass ? thi : tlo) >> (8 * w)) & 255u);  // the same for the 32 pairs of this wave
+                if (trips == 0) break;  // positions are dealt to the waves pass by pass: none in this pass, none in the next
+                const int pos = pass * (SBLK / 2) + pr;
+                int nzr = pass ? nz1 : nz0;  // bit 30: first pair of a split slot, bit 31: one of its other three pairs
+                if (pos >= np) nzr = (int)0x80000000;  // past the patch: nothing to store (its descriptors are all 0xFFFF)
                 const long long nz = nzr & 0x3fffffff;
+                unsigned dlo = pass ? d1a : d0a, dhi = pass ? d1b : d0b;
+                const int gb = pass ? g1 : g0;
                 double acc[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-                int c = cb0 + j;
-                while (c < cb1) {
-                    // (fetching the next descriptor one trip ahead was tried both ways: the conditional read makes the wait
-                    // for the current one an lgkmcnt(0), the unconditional clamped read is rotated back into this form)
-                    const int d = s_desc[c];
+#pragma nounroll
+                for (int k = 0; k < trips; ++k) {
+                    if (k >= 4 && !(k & 1)) dlo = lp[(gb + (k >> 1)) * 64];  // beyond the four prefetched trips (rare: > 8 contributions in a part)
+                    const unsigned d = dlo & 0xffffu;
+                    dlo = (dlo >> 16) | (dhi << 16);
+                    dhi >>= 16;
+                    if (d == 0xffffu) continue;
                     const int aa = (d >> 2) & 3, bb = d & 3;
                     const double* rec = s_tet + (((PROBE & 4) && (dbg & 32)) ? 0 : (d >> 4)) * SP_RS;  // probe 32: no bank conflicts
-                    double ga[3], gb[3], t0q[4], ca[4], cb[4];
+                    double ga[3], gb3[3], t0q[4], ca[4], cb[4];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        ga[k] = rec[aa * 3 + k];
-                        gb[k] = rec[bb * 3 + k];
+                    for (int i = 0; i < 3; ++i) {
+                        ga[i] = rec[aa * 3 + i];
+                        gb3[i] = rec[bb * 3 + i];
                     }
                     const d2a* r2 = reinterpret_cast<const d2a*>(rec);
                     const d2a ca01 = r2[6 + aa * 2], ca23 = r2[7 + aa * 2], cb01 = r2[6 + bb * 2], cb23 = r2[7 + bb * 2];
@@ -215,11 +217,10 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : (SBLK == 512 ? 4 : 3)) void tet_l
                     cb[0] = cb01.x; cb[1] = cb01.y; cb[2] = cb23.x; cb[3] = cb23.y;
                     t0q[0] = ta01.x; t0q[1] = ta01.y; t0q[2] = ta23.x; t0q[3] = ta23.y;
                     if ((PROBE & 4) && (dbg & 4)) {
-                        acc[0] += ga[0] + gb[1] + ca[2] + cb[3] + t0q[0] + sc.x + sc.y + cb_a + ca_b + t0_b;
+                        acc[0] += ga[0] + gb3[1] + ca[2] + cb[3] + t0q[0] + sc.x + sc.y + cb_a + ca_b + t0_b;
                     } else {
-                        lhs_block_accumulate(aa == bb, ga, gb, sc.y, t0q, sc.x, ca, cb, cb_a, ca_b, t0_b, acc);
+                        lhs_block_accumulate(aa == bb, ga, gb3, sc.y, t0q, sc.x, ca, cb, cb_a, ca_b, t0_b, acc);
                     }
-                    c += 2;
                 }
                 // reduce-scatter inside the pair: lane j ends up with the 16-byte pieces {j, j + 2, j + 4, j + 6} of the
                 // 128-byte line (entries 4k + 2j, 4k + 2j + 1) summed over both lanes, so that every store instruction
@@ -257,11 +258,11 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : (SBLK == 512 ? 4 : 3)) void tet_l
         }
         if (!has_next) break;
         nd = ndn;
-        __syncthreads();  // every wave is done with the tet records of this patch (an LDS-only barrier -- raw s_barrier behind
-                          // lgkmcnt(0), so that the row stores need not drain here -- was measured: no difference)
+        nz0 = nzn0; nz1 = nzn1;
+        d0a = dn0a; d0b = dn0b; d1a = dn1a; d1b = dn1b;
+        __syncthreads();  // every wave is done with the tet records of this patch
         h = hn; h2 = hn2; hn = hnn; hn2 = hnn2;
         p = pn; pn = pnn;
-        buf ^= 1;
     }
 }
 
@@ -664,20 +665,18 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
 extern "C" {
 
 int dfl_lhs_slot_record_bytes(void) { return SP_RS * (int)sizeof(double); }
-int64_t dfl_lhs_slot_lds_bytes(I max_tets, I max_slots, I max_contrib) { return (int64_t)slot_lds_bytes(max_tets, max_slots, max_contrib); }
+int64_t dfl_lhs_slot_lds_bytes(I max_tets) { return (int64_t)slot_lds_bytes(max_tets); }
 
 extern int g_patch_dbg;
 int g_rhs_lane_grid_cap = 0;  // developer / test knob (dfl_tune(2, n)): few workgroups make a small mesh walk the pipelined loop
-void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const I* ptet_ien, const I* slot_nz, const I* coff,
-                               const unsigned short* desc, const T* nodep, T* val, T beta, I max_tets, I max_slots,
-                               I max_contrib, void* stream) {
+void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const I* ptet_ien, const I* slot_nz, const uint32_t* ldesc,
+                               const T* nodep, T* val, T beta, I max_tets, void* stream) {
     if (npatch <= 0) return;
-    if (max_tets > SBLK || max_slots > SBLK - 1 || max_contrib > 8 * SBLK) {
-        fprintf(stderr, "dfl_assemble_tet_lhs_slot: patch limits exceeded (tets %d <= %d, slots %d <= %d, contributions %d <= %d)\n",
-                (int)max_tets, SBLK, (int)max_slots, SBLK - 1, (int)max_contrib, 8 * SBLK);
+    if (max_tets > SBLK) {
+        fprintf(stderr, "dfl_assemble_tet_lhs_slot: patch limit exceeded (tets %d <= %d)\n", (int)max_tets, SBLK);
         abort();
     }
-    const size_t lds = slot_lds_bytes(max_tets, max_slots, max_contrib);
+    const size_t lds = slot_lds_bytes(max_tets);
     // persistent grid: as many workgroups as the device keeps resident at this LDS size (re-derived when the size changes)
     static size_t lds_set = 0;
     static int resident = 0, resident_early = 0;
@@ -695,6 +694,7 @@ void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const I* ptet_ien, 
         DFL_GUARD(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernels[0], SBLK, lds));
         resident_early = cus * (occ < 1 ? 1 : occ);
         lds_set = lds;
+        if (getenv("DFL_PATCH_VERBOSE")) fprintf(stderr, "[slot kernel] %zu B LDS per workgroup, %d resident workgroups (%d EARLY) on %d CUs\n", lds, resident, resident_early, cus);
     }
     // default: the late build; dfl_tune_asm bit 16 = EARLY (node records of the next patch requested before phase 2)
     const bool early = (g_patch_dbg & 16) != 0;
@@ -704,7 +704,7 @@ void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const I* ptet_ien, 
     if (grid > need) grid = need;
     const int4* h4 = reinterpret_cast<const int4*>(hdr);
     const int4* pi4 = reinterpret_cast<const int4*>(ptet_ien);
-#define SLOT_LAUNCH(B0, PR, EA) tet_lhs_slot_kernel<B0, PR, EA><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, coff, desc, nodep, val, beta, max_tets, max_slots, max_contrib, probe)
+#define SLOT_LAUNCH(B0, PR, EA) tet_lhs_slot_kernel<B0, PR, EA><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, ldesc, nodep, val, beta, max_tets, probe)
     if (probe) {
         if (early) SLOT_LAUNCH(true, 15, true); else SLOT_LAUNCH(true, 15, false);
     } else if (beta == 0.0) {

@@ -170,8 +170,8 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
         }
         if (!x->slotpatch) x->slotpatch = DflBuildSlotPatchSchedule(mesh, spy, x->cfg.slot_leaf, x->cfg.slot_cap, x->cfg.slot_tets);
         const SlotPatchSched* ss = x->slotpatch;
-        DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_slot(ss->num_patch, ss->d_hdr, ss->d_ptet_ien, ss->d_slot_nz, ss->d_coff,
-                                                             ss->d_desc, x->nodep, val, beta_J, ss->max_tets, ss->max_slots, ss->max_contrib, s));
+        DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_slot(ss->num_patch, ss->d_hdr, ss->d_ptet_ien, ss->d_slot_nz, ss->d_ldesc,
+                                                             x->nodep, val, beta_J, ss->max_tets, s));
     }
     if (patch_rhs) { /* schedules 2, 3, 4: patch-staged residual, two launches, fixed summation order (host/patch.c) */
         const b32 wave = x->cfg.sched_mode >= 4; /* schedule 4: one wave per patch, padded layout */

@@ -55,16 +55,15 @@ typedef struct RowPatchSched {
 RowPatchSched* DflBuildRowPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap);
 void DflFreeRowPatchSchedule(RowPatchSched* ps);
 
-/* Slot-owner patch schedule (host/slotpatch.c): node patches; every nodal nonzero is summed by one lane quad. */
+/* Slot-owner patch schedule (host/slotpatch.c): node patches; every nodal nonzero is summed by one lane pair. */
 typedef struct SlotPatchSched {
     const CSRAttr* attr;
     index_type num_patch, max_tets, max_slots, max_contrib;
     int64_t total_tets;
-    int32_t* d_hdr;          /* device [num_patch][8]: tet_off, num_tet, slot_off, num_slot, contrib_off, num_contrib, 0, 0 */
+    int32_t* d_hdr;          /* device [num_patch][8]: tet_off, num_tet, pos_off, num_pos, group_off, trips_lo, trips_hi, 0 */
     index_type* d_ptet_ien;  /* device [total_tets][4] node ids of every (patch, tet) pair */
-    index_type* d_slot_nz;   /* device [nnz1] nodal nonzero of each slot */
-    index_type* d_coff;      /* device [nnz1+1] contribution offsets, slot order */
-    uint16_t* d_desc;        /* device [16T] (local tet << 4) | (a << 2) | b */
+    index_type* d_slot_nz;   /* device [positions] nodal nonzero of each slot position (+ split flags) */
+    uint32_t* d_ldesc;       /* device lane-major descriptor groups: [group][64 lanes] x 2 x ((local tet << 4) | (a << 2) | b) */
 } SlotPatchSched;
 SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap, index_type tet_cap);
 void DflFreeSlotPatchSchedule(SlotPatchSched* ps);

@@ -14,13 +14,17 @@
  * (geometry is recomputed from the node records, so moving meshes need no invalidation).
  *
  * Layout produced here (all device arrays):
- *   hdr[p]      = {tet_off, num_tet, slot_off, num_slot, contrib_off, num_contrib, 0, 0}
+ *   hdr[p]      = {tet_off, num_tet, pos_off, num_pos, group_off, trips_lo, trips_hi, 0}
  *   ptet_ien    [sum num_tet][4]  node ids of every (patch, tet) pair, ascending element id inside a patch
- *   slot_nz     [nnz1]            nodal nonzero of every slot; inside a patch the slots are sorted by contribution
+ *   slot_nz     [positions]       nodal nonzero of every slot position; inside a patch the slots are sorted by contribution
  *                                 count (descending) and dealt to the waves in snake order, so that the 32 lane
  *                                 pairs of a wave see equal trip counts
- *   coff        [nnz1 + 1]        contribution offsets in slot order
- *   desc        [16 T]            (local tet << 4) | (a << 2) | b, ascending local tet inside a slot
+ *   ldesc       lane-major contribution descriptors, (local tet << 4) | (a << 2) | b, 0xFFFF = none.  Position q of a patch
+ *               belongs to pass q / 128, wave (q % 128) / 32, lane pair q % 32; lane 2 pair + j walks contributions j, j + 2,
+ *               ... of the position's list (ascending local tet).  For every (pass, wave) of the patch, pass-major, with T =
+ *               the largest trip count among the wave's 32 pairs (trips_lo / trips_hi: one byte per (pass, wave)):
+ *               ceil(T / 2) groups of [64 lanes] x {trip 2g, trip 2g + 1} (one 32-bit word per lane and group).  The kernel
+ *               reads a lane's descriptors with coalesced word loads one patch ahead -- no offset list, no LDS staging.
  */
 #include <string.h>
 #include <omp.h>
@@ -200,7 +204,7 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
             if (vp[idx[i] + 1] - vp[idx[i]] >= SPLIT_MIN) ns += 3;
         }
         ASSERT(ns <= DFL_SLOT_BLOCK - 1 || x.out[p].hi - x.out[p].lo == 1);
-        ASSERT(nt_of[p] <= 4095 && "slot-patch descriptors hold 12-bit local tet ids");
+        ASSERT(nt_of[p] <= 4094 && "slot-patch descriptors hold 12-bit local tet ids (0xFFFF = none)");
         hdr[8 * p + 0] = (int32_t)tot_t;
         hdr[8 * p + 1] = nt_of[p];
         hdr[8 * p + 2] = (int32_t)tot_s;
@@ -352,6 +356,58 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
         free(tets_of[p]);
     }
     coff[tot_s] = (index_type)cbase[P];
+    /* lane-major descriptor groups (see the layout comment): sizes, offsets, fill */
+    const index_type pass_pairs = DFL_SLOT_BLOCK / 2, nwave_blk = DFL_SLOT_BLOCK / 64;
+    ASSERT(2 * nwave_blk <= 8 && "one trip byte per (pass, wave): trips_lo / trips_hi hold eight");
+    int64_t* gbase = (int64_t*)malloc(sizeof(int64_t) * ((size_t)P + 1));
+    gbase[0] = 0;
+    for (index_type p = 0; p < P; ++p) gbase[p + 1] = 0;
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (index_type p = 0; p < P; ++p) {
+        const index_type s0 = hdr[8 * p + 2], np = hdr[8 * p + 3];
+        uint32_t tb[2] = {0, 0};
+        int64_t groups = 0;
+        for (index_type q = 0; q < 2 * nwave_blk; ++q) {
+            const index_type first = (q / nwave_blk) * pass_pairs + (q % nwave_blk) * 32;
+            index_type maxc = 0;
+            for (index_type k = first; k < first + 32 && k < np; ++k) {
+                const index_type c = coff[s0 + k + 1] - coff[s0 + k];
+                if (c > maxc) maxc = c;
+            }
+            const index_type trips = (maxc + 1) / 2;
+            ASSERT(trips <= 254 && "slot-patch trip counts are bytes");
+            tb[q >> 2] |= (uint32_t)trips << (8 * (q & 3));
+            groups += (trips + 1) / 2;
+        }
+        hdr[8 * p + 5] = (int32_t)tb[0];
+        hdr[8 * p + 6] = (int32_t)tb[1];
+        gbase[p + 1] = groups;
+    }
+    for (index_type p = 0; p < P; ++p) gbase[p + 1] += gbase[p];
+    ASSERT(gbase[P] < 2147483647LL);
+    const size_t ld_words = ((size_t)gbase[P] + 4) * 64; /* + 4 groups: the kernel's clamped prefetch may read past the last group */
+    uint32_t* ldesc = (uint32_t*)malloc(sizeof(uint32_t) * ld_words);
+    memset(ldesc, 0xff, sizeof(uint32_t) * ld_words);
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (index_type p = 0; p < P; ++p) {
+        const index_type s0 = hdr[8 * p + 2], np = hdr[8 * p + 3];
+        const uint32_t tb[2] = {(uint32_t)hdr[8 * p + 5], (uint32_t)hdr[8 * p + 6]};
+        hdr[8 * p + 4] = (int32_t)gbase[p];
+        int64_t g0 = gbase[p];
+        for (index_type q = 0; q < 2 * nwave_blk; ++q) {
+            const index_type trips = (index_type)((tb[q >> 2] >> (8 * (q & 3))) & 255u);
+            const index_type first = (q / nwave_blk) * pass_pairs + (q % nwave_blk) * 32;
+            uint16_t* base = (uint16_t*)(ldesc + (size_t)g0 * 64);
+            for (index_type k = first; k < first + 32 && k < np; ++k) {
+                const index_type c0 = coff[s0 + k], c = coff[s0 + k + 1] - c0;
+                for (index_type i = 0; i < c; ++i) { /* contribution i: lane 2 (k - first) + (i & 1), trip i / 2 */
+                    const index_type lane = 2 * (k - first) + (i & 1), trip = i >> 1;
+                    base[((size_t)(trip >> 1) * 64 + lane) * 2 + (trip & 1)] = desc[c0 + i];
+                }
+            }
+            g0 += (trips + 1) / 2;
+        }
+    }
     ps->num_patch = P;
     ps->max_tets = maxt;
     ps->max_slots = maxs;
@@ -359,14 +415,16 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     ps->total_tets = tot_t;
     ps->d_hdr = (int32_t*)CdamMallocDevice((ptrdiff_t)P * 8 * (ptrdiff_t)sizeof(int32_t) + 32);
     ps->d_ptet_ien = (index_type*)CdamMallocDevice((ptrdiff_t)(tot_t > 0 ? tot_t : 1) * 4 * SIZE_OF(index_type));
-    ps->d_slot_nz = (index_type*)CdamMallocDevice((ptrdiff_t)tot_s * SIZE_OF(index_type));
-    ps->d_coff = (index_type*)CdamMallocDevice(((ptrdiff_t)tot_s + 1) * SIZE_OF(index_type));
-    ps->d_desc = (uint16_t*)CdamMallocDevice((ptrdiff_t)T * 16 * (ptrdiff_t)sizeof(uint16_t));
+    ps->d_slot_nz = (index_type*)CdamMallocDevice(((ptrdiff_t)tot_s + DFL_SLOT_BLOCK) * SIZE_OF(index_type));
+    ps->d_ldesc = (uint32_t*)CdamMallocDevice((ptrdiff_t)ld_words * (ptrdiff_t)sizeof(uint32_t));
     HIPGUARD(hipMemcpy(ps->d_hdr, hdr, sizeof(int32_t) * 8 * (size_t)P, H2D));
     HIPGUARD(hipMemcpy(ps->d_ptet_ien, ptet_ien, sizeof(index_type) * 4 * (size_t)tot_t, H2D));
     HIPGUARD(hipMemcpy(ps->d_slot_nz, slot_nz, sizeof(index_type) * (size_t)tot_s, H2D));
-    HIPGUARD(hipMemcpy(ps->d_coff, coff, sizeof(index_type) * ((size_t)tot_s + 1), H2D));
-    HIPGUARD(hipMemcpy(ps->d_desc, desc, sizeof(uint16_t) * (size_t)T * 16, H2D));
+    HIPGUARD(hipMemcpy(ps->d_ldesc, ldesc, sizeof(uint32_t) * ld_words, H2D));
+    if (verbose)
+        fprintf(stderr, "[slotpatch] %.1f descriptor groups per patch, %.0f %% of their entries used\n", (double)gbase[P] / (double)(P > 0 ? P : 1),
+                100.0 * 16.0 * (double)T / (128.0 * (double)(gbase[P] > 0 ? gbase[P] : 1)));
+    free(ldesc); free(gbase);
     if (verbose) fprintf(stderr, "[slotpatch] uploaded at %.2f s\n", omp_get_wtime() - t0);
     free(cbase); free(desc); free(coff); free(slot_nz); free(ptet_ien); free(hdr); free(nt_of); free(tets_of);
     free(x.out); free(idx); free(ve); free(vp); free(ci); free(rp);
@@ -376,6 +434,6 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
 void DflFreeSlotPatchSchedule(SlotPatchSched* ps) {
     if (!ps) return;
     CdamFreeDevice(ps->d_hdr, 0); CdamFreeDevice(ps->d_ptet_ien, 0); CdamFreeDevice(ps->d_slot_nz, 0);
-    CdamFreeDevice(ps->d_coff, 0); CdamFreeDevice(ps->d_desc, 0);
+    CdamFreeDevice(ps->d_ldesc, 0);
     CdamFreeHost(ps, SIZE_OF(SlotPatchSched));
 }

@@ -23,7 +23,7 @@ L.MatrixZero(P.J)
 P.assemble_tet(wg_d, dwg_d, None, want_J=True)
 api.sync()
 REPS = int(os.environ.get('DFL_DBG_REPS', 20))
-seq = tuple(int(v) for v in sys.argv[3].split(',')) if len(sys.argv) > 3 else ((256, 272, 257, 258, 259, 260, 262, 264, 268, 288, 256) if mode == 4 else (0, 8, 2, 10, 1, 3, 0))
+seq = ((256,) if mode == 4 else (0,)) if len(sys.argv) > 3 and sys.argv[3] == 'pmc' else tuple(int(v) for v in sys.argv[3].split(',')) if len(sys.argv) > 3 else ((256, 272, 257, 258, 259, 260, 262, 264, 268, 288, 256) if mode == 4 else (0, 8, 2, 10, 1, 3, 0))
 for dbg in seq:
     L.dfl_tune_asm(dbg)
     for rep in range(3):
