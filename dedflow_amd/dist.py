@@ -335,23 +335,39 @@ class RcclSolverComm:
         L.DflRcclCommVtable.restype, L.DflRcclCommVtable.argtypes = vp, [vp]
         L.DflRcclCommCounters.restype, L.DflRcclCommCounters.argtypes = None, [vp, vp, vp]
         L.DflRcclCommDestroy.restype, L.DflRcclCommDestroy.argtypes = None, [vp]
+        # Every rank walks the same sequence of collectives whatever fails locally (a rank that raised before a collective
+        # the others entered would leave them waiting): local failures are recorded in `ok` and agreed on at the end.
         bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         path = bundled if os.path.exists(bundled) else ""     # the RCCL build torch already runs on
+        ok, why = True, ""
         if L.DflRcclLoad(path.encode()) != 0:
-            raise RuntimeError("RCCL could not be loaded from %r" % path)
+            ok, why = False, "RCCL could not be loaded from %r" % path
         nbytes = L.DflRcclUniqueIdBytes()
         box = [b"", b""]     # two ids: all-reduce communicator, halo communicator (own stream)
-        if plan.rank == 0:
+        if plan.rank == 0 and ok:
             for k in range(2):
                 buf = C.create_string_buffer(nbytes)
                 if L.DflRcclGetUniqueId(buf) != 0:
-                    raise RuntimeError("ncclGetUniqueId failed")
+                    ok, why = False, "ncclGetUniqueId failed"
+                    box = [b"", b""]
+                    break
                 box[k] = bytes(buf.raw)
         dist.broadcast_object_list(box, src=0)
         torch.cuda.synchronize()
-        self.c = L.DflRcclCommCreate(box[0], plan.rank, plan.world)
-        if not self.c:
-            raise RuntimeError("DflRcclCommCreate failed")
+        self.c = None
+        if ok and len(box[0]) == nbytes and len(box[1]) == nbytes:   # rank 0 had no id: nobody creates a communicator
+            self.c = L.DflRcclCommCreate(box[0], plan.rank, plan.world)
+            if not self.c:
+                ok, why = False, "DflRcclCommCreate failed"
+        else:
+            ok, why = False, why or "rank 0 could not create the RCCL unique ids"
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 0.5:
+            if self.c:
+                L.DflRcclCommDestroy(self.c)
+                self.c = None
+            raise RuntimeError(why or "the RCCL communicator failed on another rank")   # raised on EVERY rank
         L.DflRcclCommCreateHaloComm.restype, L.DflRcclCommCreateHaloComm.argtypes = None, [vp, C.c_char_p]
         L.DflRcclCommCreateHaloComm(self.c, box[1])
         sc = np.asarray(plan.send_splits, np.int32)
