@@ -146,16 +146,16 @@ __device__ __forceinline__ void lhs_block_eval(int aa, int bb, const double* ga,
 }
 
 // acc += the 4x4 (u,p) block of node pair (aa, bb), from what the slot-owner kernel keeps per tet (shape gradients of the
-// two nodes, convective shape derivatives ca[q] / cb[q] and tauM t0[q] at the four quadrature points, the sum of tauC,
-// |det J|) plus three single entries the caller reads by index (cb[aa], ca[bb], t0[bb]).  Same terms as lhs_block_eval;
-// the sums that carry a shape-function factor collapse through shl(c, q) = SHB + (SHA - SHB)[c == q], and every entry is
-// accumulated by fused multiply-adds straight into `acc` (about 90 fp64 operations instead of ~140).
-__device__ __forceinline__ void lhs_block_accumulate(bool same, const double* ga, const double* gb, double detJ, const double* t0,
-                                                     double S_t1, const double* ca, const double* cb, double cb_a, double ca_b,
-                                                     double t0_b, double* acc) {
+// two nodes, convective shape derivatives ca[q] / cb[q] and tauM t0[q] at the four quadrature points, and four numbers
+// that are the same for the sixteen blocks of the tet: w = |det J| GW, cK = 4 fact2 mu w, cT = fact2 rho (sum of tauC) w,
+// S_t0 = sum of tauM) plus three single entries the caller reads by index (cb[aa], ca[bb], t0[bb]).  Same terms as
+// lhs_block_eval; the sums that carry a shape-function factor collapse through shl(c, q) = SHB + (SHA - SHB)[c == q], and
+// every entry is accumulated by fused multiply-adds straight into `acc` (about 85 fp64 operations instead of ~140).
+__device__ __forceinline__ void lhs_block_accumulate(bool same, const double* ga, const double* gb, double w, double cK, double cT,
+                                                     double S_t0, const double* t0, const double* ca, const double* cb, double cb_a,
+                                                     double ca_b, double t0_b, double* acc) {
     const double fact1 = kALPHAM;
     const double fact2 = kDT * kALPHAF * kGAMMA;
-    const double S_t0 = (t0[0] + t0[1]) + (t0[2] + t0[3]);
     const double tc0 = t0[0] * ca[0], tc1 = t0[1] * ca[1], tc2 = t0[2] * ca[2], tc3 = t0[3] * ca[3];
     const double S_t0ca = (tc0 + tc1) + (tc2 + tc3);
     const double S_t0cacb = fma(tc3, cb[3], fma(tc2, cb[2], fma(tc1, cb[1], tc0 * cb[0])));
@@ -167,14 +167,12 @@ __device__ __forceinline__ void lhs_block_accumulate(bool same, const double* ga
     const double S_sasb = same ? (SHA * SHA + 3.0 * SHB * SHB) : (2.0 * SHA * SHB + 2.0 * SHB * SHB);
     const double S_one = SHA + 3.0 * SHB;  // sum of the shape functions over the quadrature points
     const double eK = fma(ga[2], gb[2], fma(ga[1], gb[1], ga[0] * gb[0]));
-    const double w = detJ * GW;
     double d = (4.0 * fact2 * kMU) * eK;
     d = fma(fact2 * kRHO * kRHO, S_t0cacb, d);
     d = fma(fact2 * kRHO, S_sacb, d);
     d = fma(fact1 * kRHO * kRHO, S_t0casb, d);
     d = fma(fact1 * kRHO, S_sasb, d);
     const double diag = w * d;
-    const double cK = (4.0 * fact2 * kMU) * w, cT = (fact2 * kRHO) * S_t1 * w;
     double kgb[3], tgb[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

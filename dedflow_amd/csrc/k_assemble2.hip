@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int SBLK = DFL_SLOT_BLOCK;
-constexpr int SP_RS = 34;  // doubles per LDS tet record: shg[12] conv[a][q] (16) tauM[4] sum tauC, detJ
+constexpr int SP_RS = 36;  // doubles per LDS tet record: shg[12] conv[a][q] (16) tauM[4] | cT, w | sum tauM, cK (asm_device.hpp)
 
 typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
 
@@ -72,7 +72,7 @@ __device__ __forceinline__ void slot_tet_record(const double2* r, double* rec) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) su[d] = ((u[d] + u[3 + d]) + u[6 + d]) + u[9 + d];
     const double knu = kMU / kRHO;
-    double s_t1 = 0.0;
+    double s_t1 = 0.0, t0v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         // u at quadrature point q (qr_wgalpha, :1648-1655): shl(b,q) = SHB + (SHA-SHB)[b == q]
@@ -86,11 +86,17 @@ __device__ __forceinline__ void slot_tet_record(const double2* r, double* rec) {
         }
         // |J^-1 u|^2 (rows of J^-1 = shape gradients of nodes 1..3) and the stabilisation parameters (:587-603)
         const double y = cv[1] * cv[1] + cv[2] * cv[2] + cv[3] * cv[3] + (3.0 * knu * knu) * gg;
-        rec[28 + q] = rsqrt(4.0 / (kDT * kDT) + y) * (1.0 / kRHO);
+        t0v[q] = rsqrt(4.0 / (kDT * kDT) + y) * (1.0 / kRHO);
+        rec[28 + q] = t0v[q];
         s_t1 += y * rsqrt(y) * itr;  // tauC enters the block only through its sum over the quadrature points
     }
-    rec[32] = s_t1;
-    rec[33] = detJ;
+    // the four numbers every block of the tet starts from (lhs_block_accumulate), formed once here instead of 16 times there
+    const double fact2 = kDT * kALPHAF * kGAMMA;
+    const double w = detJ * GW;
+    rec[32] = (fact2 * kRHO) * s_t1 * w;
+    rec[33] = w;
+    rec[34] = (t0v[0] + t0v[1]) + (t0v[2] + t0v[3]);
+    rec[35] = (4.0 * fact2 * kMU) * w;
 }
 
 // PROBE != 0 only under dfl_tune_asm (developer phase split: bit 0 skip phase 2, bit 1 skip phase 1, bit 2 skip the
@@ -211,15 +217,15 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 4) void tet_lhs_slot_kernel(I P, 
                     }
                     const d2a* r2 = reinterpret_cast<const d2a*>(rec);
                     const d2a ca01 = r2[6 + aa * 2], ca23 = r2[7 + aa * 2], cb01 = r2[6 + bb * 2], cb23 = r2[7 + bb * 2];
-                    const d2a ta01 = r2[14], ta23 = r2[15], sc = r2[16];
+                    const d2a ta01 = r2[14], ta23 = r2[15], sc = r2[16], sk = r2[17];
                     const double cb_a = rec[12 + bb * 4 + aa], ca_b = rec[12 + aa * 4 + bb], t0_b = rec[28 + bb];
                     ca[0] = ca01.x; ca[1] = ca01.y; ca[2] = ca23.x; ca[3] = ca23.y;
                     cb[0] = cb01.x; cb[1] = cb01.y; cb[2] = cb23.x; cb[3] = cb23.y;
                     t0q[0] = ta01.x; t0q[1] = ta01.y; t0q[2] = ta23.x; t0q[3] = ta23.y;
                     if ((PROBE & 4) && (dbg & 4)) {
-                        acc[0] += ga[0] + gb3[1] + ca[2] + cb[3] + t0q[0] + sc.x + sc.y + cb_a + ca_b + t0_b;
+                        acc[0] += ga[0] + gb3[1] + ca[2] + cb[3] + t0q[0] + sc.x + sc.y + sk.x + sk.y + cb_a + ca_b + t0_b;
                     } else {
-                        lhs_block_accumulate(aa == bb, ga, gb3, sc.y, t0q, sc.x, ca, cb, cb_a, ca_b, t0_b, acc);
+                        lhs_block_accumulate(aa == bb, ga, gb3, sc.y, sk.y, sc.x, sk.x, t0q, ca, cb, cb_a, ca_b, t0_b, acc);
                     }
                 }
                 // reduce-scatter inside the pair: lane j ends up with the 16-byte pieces {j, j + 2, j + 4, j + 6} of the
