@@ -17,6 +17,8 @@
 #include <float.h>
 #include <math.h>
 #include <string.h>
+#include <unistd.h>
+#include <omp.h>
 #include "dedflow.h"
 #include "dedflow_kernels.h"
 #include "host_private.h"
@@ -433,8 +435,8 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     int best = 0;
     /* the SpMV output goes to eight columns spread over the block (a block is not always of one kind from end to end: with
        three sample columns a candidate scored 0.604 ms and then ran at 0.643 ms); a candidate's score is their mean */
-#define TIME_CANDIDATES(out_ms)                                                                      \
-    for (int k = 0; k < n; ++k) {                                                                    \
+#define TIME_CANDIDATE(k, out)                                                                       \
+    {                                                                                                \
         f64* Qk = cand[k];                                                                           \
         f64* w = Qk + (size_t)6 * (size_t)na;                                                        \
         float sum_ms = 0.f;                                                                          \
@@ -452,59 +454,101 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
             HIPGUARD(hipEventElapsedTime(&ms, a, b));                                                \
             if (rep > 0) sum_ms += ms;                                                               \
         }                                                                                            \
-        out_ms[k] = sum_ms / 8.f;                                                                    \
+        (out) = sum_ms / 8.f;                                                                        \
     }
-    TIME_CANDIDATES(best_ms)
-    for (int k = 1; k < n; ++k)
-        if (best_ms[k] < best_ms[best]) best = k;
-    const int best_in_place = best;
-    /* The value array has a placement of its own: whole processes were measured in which the SpMV took 0.67 ms with the
+#define TIME_CANDIDATES(out_ms) \
+    for (int k = 0; k < n; ++k) TIME_CANDIDATE(k, out_ms[k])
+    /* Device memory that is freed is wiped by the driver in the background, and while that runs the in-loop SpMV takes
+       0-8 % longer, unevenly (tools/probe_clocks.py: the spacers above are ~250 GB; the SOC clock sits at 1200 MHz instead of
+       < 100 MHz, the idle board draws 50 W more, for 3-4 s after the last free -- whether the GPU works or idles meanwhile).
+       Timing candidates, or handing the work space to a solver, in that state measures the wipe.  So: sample the loop on one
+       candidate every 250 ms until three samples in a row agree to 0.4 % (at most DFL_WS_SETTLE_S seconds, default 8, 0 =
+       off); once here, before the candidates are compared, and once at the end, after the losers have been freed. */
+    double settle_cap = 8.0;
+    { const char* es = getenv("DFL_WS_SETTLE_S"); if (es) settle_cap = atof(es); }
+    double settled_s[2] = {0.0, 0.0};
+    float settled_ms[2] = {0.f, 0.f};
+#define SETTLE(k, which)                                                                             \
+    if (settle_cap > 0.0) {                                                                          \
+        float h0 = -1.f, h1 = -1.f, cur = 0.f;                                                       \
+        const double t_begin = omp_get_wtime();                                                      \
+        for (;;) {                                                                                   \
+            TIME_CANDIDATE(k, cur)                                                                   \
+            const b32 calm = h0 > 0.f && h1 > 0.f && fabsf(cur - h0) < 0.004f * cur && fabsf(cur - h1) < 0.004f * cur && \
+                             fabsf(h0 - h1) < 0.004f * cur;                                          \
+            if (calm || omp_get_wtime() - t_begin > settle_cap) break;                               \
+            h1 = h0; h0 = cur;                                                                       \
+            usleep(250000);                                                                          \
+        }                                                                                            \
+        settled_s[which] = omp_get_wtime() - t_begin;                                                \
+        settled_ms[which] = cur;                                                                     \
+    }
+    /* the value array has a placement of its own: whole processes were measured in which the SpMV took 0.67 ms with the
        array where the allocator's pool put it, whatever the output vector, and 0.57 ms with a plain hipMalloc copy
-       (tools/probe_spmv_r2f.py).  So the same piece of the loop is timed once more on a heap copy of the values, and the
-       matrix moves there if that is at least 3 % faster (DFL_VAL_RELOCATE=0 keeps it where it is). */
+       (tools/probe_spmv_r2f.py).  So copies of the values are made -- a plain block, and one behind a spacer of a third of
+       the free memory -- BEFORE anything is timed (their spacer is the last big free), the same piece of the loop is timed
+       on them too, and the matrix moves if that is at least 3 % faster (DFL_VAL_RELOCATE=0 keeps it where it is). */
     float moved_ms[2][8];
     int moved = 0, moved_tested = 0;
+    void* hv[2] = {NULL, NULL};
+    MatrixFS* fs = (MatrixFS*)A->data;
+    f64* const old_val = fs->block_val;
     {
-        MatrixFS* fs = (MatrixFS*)A->data;
         const size_t vbytes = (size_t)fs->spy1x1->nnz * 16 * sizeof(f64);
         size_t free_b = 0, total_b = 0;
         const char* ev = getenv("DFL_VAL_RELOCATE");
         if (!(ev && atoi(ev) == 0) && !fs->block_val_heap && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
             free_b > 3 * vbytes + ((size_t)4 << 30)) {
-            f64* const old = fs->block_val;
-            void* hv[2] = {NULL, NULL}; /* a plain block, and one behind a spacer of a third of the free memory */
-            float hv_best[2] = {1e30f, 1e30f};
-            int hv_k[2] = {0, 0};
             for (int v = 0; v < 2; ++v) {
                 void* spacer = NULL;
-                if (v == 1 && hipMalloc(&spacer, free_b / 3) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
+                if (v == 1) {
+                    if (ncand < 5) continue; /* DFL_WS_CANDIDATES < 5: no far placements, no spacers */
+                    if (hipMalloc(&spacer, free_b / 3) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
+                }
                 if (hipMalloc(&hv[v], vbytes) != hipSuccess) { (void)hipGetLastError(); hv[v] = NULL; }
                 if (spacer) HIPGUARD(hipFree(spacer));
-                if (!hv[v]) continue;
-                HIPGUARD(hipMemcpyAsync(hv[v], old, vbytes, D2D, s));
-                fs->block_val = (f64*)hv[v]; /* timed in place of the original; nothing else runs meanwhile */
-                TIME_CANDIDATES(moved_ms[v])
-                fs->block_val = old;
-                moved_tested |= 1 << v;
-                for (int k = 0; k < n; ++k)
-                    if (moved_ms[v][k] < hv_best[v]) { hv_best[v] = moved_ms[v][k]; hv_k[v] = k; }
+                if (hv[v]) HIPGUARD(hipMemcpyAsync(hv[v], old_val, vbytes, D2D, s));
             }
-            const int vb = hv_best[1] < hv_best[0] ? 1 : 0;
-            if (hv[vb] && hv_best[vb] < 0.97f * best_ms[best]) {
-                DflMatrixFSRelocateBlockValues(A, (f64*)hv[vb]);
-                best = hv_k[vb];
-                moved = 1 + vb;
-                hv[vb] = NULL;
-            }
-            for (int v = 0; v < 2; ++v)
-                if (hv[v]) HIPGUARD(hipFree(hv[v]));
         }
     }
+    SETTLE(0, 0)
+    TIME_CANDIDATES(best_ms)
+    for (int k = 1; k < n; ++k)
+        if (best_ms[k] < best_ms[best]) best = k;
+    const int best_in_place = best;
+    {
+        float hv_best[2] = {1e30f, 1e30f};
+        int hv_k[2] = {0, 0};
+        for (int v = 0; v < 2; ++v) {
+            if (!hv[v]) continue;
+            fs->block_val = (f64*)hv[v]; /* timed in place of the original; nothing else runs meanwhile */
+            TIME_CANDIDATES(moved_ms[v])
+            fs->block_val = old_val;
+            moved_tested |= 1 << v;
+            for (int k = 0; k < n; ++k)
+                if (moved_ms[v][k] < hv_best[v]) { hv_best[v] = moved_ms[v][k]; hv_k[v] = k; }
+        }
+        const int vb = hv_best[1] < hv_best[0] ? 1 : 0;
+        if (hv[vb] && hv_best[vb] < 0.97f * best_ms[best]) {
+            DflMatrixFSRelocateBlockValues(A, (f64*)hv[vb]);
+            best = hv_k[vb];
+            moved = 1 + vb;
+            hv[vb] = NULL;
+        }
+        for (int v = 0; v < 2; ++v)
+            if (hv[v]) HIPGUARD(hipFree(hv[v]));
+    }
+    HIPGUARD(hipStreamSynchronize(s));
+    for (int k = 0; k < n; ++k)
+        if (k != best) ws_vec_free_as(cand[k], pooled[k]);
+    SETTLE(best, 1)
+#undef SETTLE
 #undef TIME_CANDIDATES
+#undef TIME_CANDIDATE
     HIPGUARD(hipEventDestroy(a));
     HIPGUARD(hipEventDestroy(b));
     if (getenv("DFL_WS_VERBOSE")) {
-        fprintf(stderr, "[krylov] basis placement: in-loop SpMV into %d candidates:", n);
+        fprintf(stderr, "[krylov] basis placement: settled after %.2f s at %.4f ms; in-loop SpMV into %d candidates:", settled_s[0], settled_ms[0], n);
         for (int k = 0; k < n; ++k) fprintf(stderr, " %.4f%s%s", best_ms[k], pooled[k] ? "(pool)" : "", k == best_in_place ? "*" : "");
         fprintf(stderr, " ms\n");
         for (int v = 0; v < 2; ++v)
@@ -513,10 +557,8 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
                 for (int k = 0; k < n; ++k) fprintf(stderr, " %.4f", moved_ms[v][k]);
                 fprintf(stderr, " ms%s\n", moved == 1 + v ? " -> moved there" : "");
             }
+        fprintf(stderr, "[krylov] losers freed; settled after %.2f s at %.4f ms\n", settled_s[1], settled_ms[1]);
     }
-    HIPGUARD(hipStreamSynchronize(s));
-    for (int k = 0; k < n; ++k)
-        if (k != best) ws_vec_free_as(cand[k], pooled[k]);
     ex->q_pooled = pooled[best];
     return cand[best]; /* all-zero: only zero vectors went through the kernels above */
 }
