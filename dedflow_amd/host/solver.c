@@ -461,24 +461,32 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     /* Device memory that is freed is wiped by the driver in the background, and while that runs the in-loop SpMV takes
        0-8 % longer, unevenly (tools/probe_clocks.py: the spacers above are ~250 GB; the SOC clock sits at 1200 MHz instead of
        < 100 MHz, the idle board draws 50 W more, for 3-4 s after the last free -- whether the GPU works or idles meanwhile).
-       Timing candidates, or handing the work space to a solver, in that state measures the wipe.  So: sample the loop on one
-       candidate every 250 ms until three samples in a row agree to 0.4 % (at most DFL_WS_SETTLE_S seconds, default 8, 0 =
-       off); once here, before the candidates are compared, and once at the end, after the losers have been freed. */
-    double settle_cap = 8.0;
+       The wipe comes in episodes of 0.15-0.25 s with calm stretches of ~0.5 s in between (rocprofv3 trace of the bench:
+       steps at 0.644 and 0.5965 ms alternating in blocks).  Timing candidates, or handing the work space to a solver, in that
+       state measures the wipe.  So: sample the loop on one candidate every 100 ms until the last twenty samples (2 s) lie
+       within 2.5 % of each other (a calm loop scatters by +-1 % from sample to sample, an episode adds 8 %; at most
+       DFL_WS_SETTLE_S seconds, default 10, 0 = off); once here, before the candidates are compared, and once at the end,
+       after the losers have been freed. */
+    double settle_cap = 10.0;
     { const char* es = getenv("DFL_WS_SETTLE_S"); if (es) settle_cap = atof(es); }
     double settled_s[2] = {0.0, 0.0};
     float settled_ms[2] = {0.f, 0.f};
 #define SETTLE(k, which)                                                                             \
     if (settle_cap > 0.0) {                                                                          \
-        float h0 = -1.f, h1 = -1.f, cur = 0.f;                                                       \
+        float hist[20], cur = 0.f;                                                                   \
+        int nh = 0;                                                                                  \
         const double t_begin = omp_get_wtime();                                                      \
         for (;;) {                                                                                   \
             TIME_CANDIDATE(k, cur)                                                                   \
-            const b32 calm = h0 > 0.f && h1 > 0.f && fabsf(cur - h0) < 0.004f * cur && fabsf(cur - h1) < 0.004f * cur && \
-                             fabsf(h0 - h1) < 0.004f * cur;                                          \
-            if (calm || omp_get_wtime() - t_begin > settle_cap) break;                               \
-            h1 = h0; h0 = cur;                                                                       \
-            usleep(250000);                                                                          \
+            hist[nh % 20] = cur;                                                                     \
+            ++nh;                                                                                    \
+            float lo = cur, hi = cur;                                                                \
+            for (int i = 0; i < (nh < 20 ? nh : 20); ++i) {                                          \
+                if (hist[i] < lo) lo = hist[i];                                                      \
+                if (hist[i] > hi) hi = hist[i];                                                      \
+            }                                                                                        \
+            if ((nh >= 20 && hi - lo < 0.025f * lo) || omp_get_wtime() - t_begin > settle_cap) break; \
+            usleep(100000);                                                                          \
         }                                                                                            \
         settled_s[which] = omp_get_wtime() - t_begin;                                                \
         settled_ms[which] = cur;                                                                     \
