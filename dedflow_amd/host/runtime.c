@@ -4,6 +4,8 @@
  * on this path; the "handle" slots hand out the library stream. */
 #include <dlfcn.h>
 #include <string.h>
+#include <unistd.h>
+#include <omp.h>
 #include "dedflow.h"
 #include "dedflow_kernels.h"
 
@@ -28,6 +30,96 @@ void DflGuardPrivate(hipError_t code, const char* file, int line) {
     }
 }
 
+/* ---- "is the driver still wiping freed device memory?" ---------------------------------------------------------------
+ * Device memory that a process frees (or leaves behind when it exits) is wiped by the driver in the background at about
+ * 36 GB/s before it is handed out again; meanwhile streaming kernels run 0-8 % slower in episodes, the SOC clock sits at
+ * 1200 MHz, and allocations made in that state land where the wipe has already been (tools/probe_exit_wipe.py,
+ * tools/probe_clocks.py).  hipMemGetInfo does not see it (it counts the memory as free at once); the
+ * driver's own "VRAM used" figure does, and rocm_smi reads it (read-only, no privileges).  rocm_smi is bound at run time
+ * like RCCL and ROCTx; when it is missing every function below reports "unknown" and nobody waits. */
+static struct {
+    int state; /* 0 = not tried, 1 = usable, -1 = unavailable */
+    uint32_t dv;
+    int (*mem_usage)(uint32_t, int, uint64_t*);
+    int (*clk_freq)(uint32_t, int, void*);
+} g_smi;
+typedef struct { uint8_t has_deep_sleep; uint32_t num_supported, current; uint64_t frequency[33]; } SmiFrequencies; /* rsmi_frequencies_t */
+
+static void smi_bind(void) {
+    if (g_smi.state) return;
+    g_smi.state = -1;
+    if (getenv("DFL_NO_SMI")) return;
+    void* h = dlopen("librocm_smi64.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librocm_smi64.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librocm_smi64.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    int (*init)(uint64_t) = (int (*)(uint64_t))dlsym(h, "rsmi_init");
+    int (*num)(uint32_t*) = (int (*)(uint32_t*))dlsym(h, "rsmi_num_monitor_devices");
+    int (*pci)(uint32_t, uint64_t*) = (int (*)(uint32_t, uint64_t*))dlsym(h, "rsmi_dev_pci_id_get");
+    *(void**)(&g_smi.mem_usage) = dlsym(h, "rsmi_dev_memory_usage_get");
+    *(void**)(&g_smi.clk_freq) = dlsym(h, "rsmi_dev_gpu_clk_freq_get");
+    if (!init || !num || !pci || !g_smi.mem_usage || init(0) != 0) return;
+    /* the rocm_smi index of the current HIP device: match PCI domain : bus : device . function */
+    int dev = 0;
+    char bus[64] = {0};
+    unsigned dom = 0, b = 0, d = 0, f = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) return;
+    uint32_t n = 0;
+    if (num(&n) != 0) return;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t id = 0;
+        if (pci(i, &id) != 0) continue;
+        if ((unsigned)(id >> 32) == dom && (unsigned)((id >> 8) & 0xff) == b && (unsigned)((id >> 3) & 0x1f) == d && (unsigned)(id & 7) == f) {
+            g_smi.dv = i;
+            g_smi.state = 1;
+            return;
+        }
+    }
+}
+
+/* bytes of VRAM the driver counts as in use on the current device, INCLUDING memory that was freed but is not wiped yet;
+ * -1 when unknown */
+int64_t DflDeviceMemoryInUse(void) {
+    smi_bind();
+    uint64_t used = 0;
+    if (g_smi.state != 1 || g_smi.mem_usage(g_smi.dv, 0 /* RSMI_MEM_TYPE_VRAM */, &used) != 0) return -1;
+    return (int64_t)used;
+}
+
+/* 1 while the SOC clock is at its high level (>= 600 MHz; it idles and computes below 150 MHz): the second sign of a wipe,
+ * and the only one for memory freed inside the running process (that leaves the "in use" figure at once); 0 otherwise or
+ * when unknown */
+static int smi_soc_clock_high(void) {
+    SmiFrequencies f;
+    memset(&f, 0, sizeof f);
+    if (g_smi.state != 1 || !g_smi.clk_freq || g_smi.clk_freq(g_smi.dv, 3 /* RSMI_CLK_TYPE_SOC */, &f) != 0 || f.current >= 33) return 0;
+    return f.frequency[f.current] >= 600000000ull;
+}
+
+/* Blocks while a wipe is in progress -- the "in use" figure FALLING (nothing of ours is being freed meanwhile) or the SOC
+ * clock high -- at most max_seconds.  Returns the seconds waited, 0 when there was no sign of one, -1 when rocm_smi is
+ * unavailable.  A first look of 60 ms decides whether to wait at all; the wait ends after 0.4 s without either sign. */
+double DflWaitDeviceMemoryQuiet(double max_seconds) {
+    int64_t prev = DflDeviceMemoryInUse();
+    if (prev < 0) return -1.0;
+    const double t0 = omp_get_wtime();
+    const int64_t step = (int64_t)64 << 20;
+    usleep(60000);
+    int64_t cur = DflDeviceMemoryInUse();
+    if (cur < 0) return -1.0;
+    if (prev - cur < step && !smi_soc_clock_high()) return 0.0;
+    int calm = 0;
+    while (calm < 8 && omp_get_wtime() - t0 < max_seconds) {
+        prev = cur;
+        usleep(50000);
+        cur = DflDeviceMemoryInUse();
+        if (cur < 0) return -1.0;
+        calm = (prev - cur < step && !smi_soc_clock_high()) ? calm + 1 : 0;
+    }
+    return omp_get_wtime() - t0;
+}
+
 void Init(int argc, char** argv) {
     UNUSED(argc);
     UNUSED(argv);
@@ -40,6 +132,15 @@ void Init(int argc, char** argv) {
         abort();
     }
     g_initialised = 1;
+    /* a predecessor's memory may still be under the driver's wipe: wait for that before anything is placed */
+    {
+        const char* eq = getenv("DFL_INIT_QUIET_S");
+        const double cap = eq ? atof(eq) : 30.0;
+        if (cap > 0.0) {
+            const double w = DflWaitDeviceMemoryQuiet(cap);
+            if (w > 0.0 && getenv("DFL_WS_VERBOSE")) fprintf(stderr, "[init] waited %.2f s for the driver to finish wiping freed device memory\n", w);
+        }
+    }
     /* reserve the first pool chunk while VRAM is pristine (see "device memory pool" below) */
     pool_configure();
     if (g_pool_state == 1 && g_nchunk == 0) (void)pool_new_chunk(g_chunk_bytes);

@@ -463,8 +463,9 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
        < 100 MHz, the idle board draws 50 W more, for 3-4 s after the last free -- whether the GPU works or idles meanwhile).
        The wipe comes in episodes of 0.15-0.25 s with calm stretches of ~0.5 s in between (rocprofv3 trace of the bench:
        steps at 0.644 and 0.5965 ms alternating in blocks).  Timing candidates, or handing the work space to a solver, in that
-       state measures the wipe.  So: sample the loop on one candidate every 100 ms until the last twenty samples (2 s) lie
-       within 2.5 % of each other (a calm loop scatters by +-1 % from sample to sample, an episode adds 8 %; at most
+       state measures the wipe.  So: wait until the driver's "VRAM in use" figure has stopped falling (DflWaitDeviceMemoryQuiet,
+       host/runtime.c: it counts freed memory until it is wiped, ~36 GB/s); without rocm_smi, sample the loop on one candidate
+       every 100 ms until the last twenty samples (2 s) lie within 2.5 % of each other (a calm loop scatters by +-1 % from sample to sample, an episode adds 8 %; at most
        DFL_WS_SETTLE_S seconds, default 10, 0 = off); once here, before the candidates are compared, and once at the end,
        after the losers have been freed. */
     double settle_cap = 10.0;
@@ -472,7 +473,9 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     double settled_s[2] = {0.0, 0.0};
     float settled_ms[2] = {0.f, 0.f};
 #define SETTLE(k, which)                                                                             \
-    if (settle_cap > 0.0) {                                                                          \
+    if (settle_cap > 0.0 && (settled_s[which] = DflWaitDeviceMemoryQuiet(settle_cap + 20.0)) >= 0.0) {  \
+        TIME_CANDIDATE(k, settled_ms[which]) /* the driver's own figure says the wipe is over */   \
+    } else if (settle_cap > 0.0) {            /* no rocm_smi: judge by the loop itself */         \
         float hist[20], cur = 0.f;                                                                   \
         int nh = 0;                                                                                  \
         const double t_begin = omp_get_wtime();                                                      \
