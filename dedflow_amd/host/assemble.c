@@ -16,7 +16,7 @@ static b32 g_quiet = FALSE;
  *   schedule 4  nodes per patch, nodal nonzeros and tets per patch (one slot offset / one tet per lane of a 256-thread
  *               workgroup: <= 255 / <= 256); residual: one wave per patch of (tets, nodes) = (16,32), (32,48) or (64,64)
  *   face group  boundary group whose faces carry the weak-BC terms (the reference hard-codes group 4) */
-static AsmConfig g_asm = {4, 4, 96, 448, 16, 255, 10, 200, 128, 64, 64, 64, 64};
+static AsmConfig g_asm = {4, 4, 96, 448, 16, 255, 7, 200, 128, 64, 64, 64, 64};
 const AsmConfig* DflAsmDefaults(void) { return &g_asm; }
 void DflSetAssemblySchedule(int mode) { g_asm.sched_mode = mode; }
 void DflSetPatchParameters(index_type leaf, index_type slot_cap) {
