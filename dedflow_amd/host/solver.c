@@ -527,6 +527,9 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     for (int k = 1; k < n; ++k)
         if (best_ms[k] < best_ms[best]) best = k;
     const int best_in_place = best;
+    const int n_round1 = n;
+    int pooled1[8];
+    for (int k = 0; k < 8; ++k) pooled1[k] = k < n ? pooled[k] : 0;
     {
         float hv_best[2] = {1e30f, 1e30f};
         int hv_k[2] = {0, 0};
@@ -553,22 +556,74 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     for (int k = 0; k < n; ++k)
         if (k != best) ws_vec_free_as(cand[k], pooled[k]);
     SETTLE(best, 1)
+    /* Second round.  The placement is drawn afresh per allocation, and on a box that has been used the first draw is often
+       poor all round (behind the 50M-tet tests: 0.68-0.72 ms for every candidate in place, 0.636 ms after the value array
+       had moved -- and 0.591 ms for the NEXT work space of the same process, allocated after that move).  So with the
+       value array where it now stays, up to three more blocks are drawn behind spacers of other sizes, timed next to the
+       winner in one quiet stretch, and the fastest of the four is kept (DFL_WS_ROUND2=0 skips it). */
+    float round2_ms[4] = {0.f, 0.f, 0.f, 0.f};
+    int round2_n = 0, round2_pick = 0;
+    {
+        const char* e2 = getenv("DFL_WS_ROUND2");
+        if (ncand >= 5 && !(e2 && atoi(e2) == 0)) {
+            f64* const win = cand[best];
+            const int win_pooled = pooled[best];
+            cand[0] = win;
+            pooled[0] = win_pooled;
+            n = 1;
+            for (int extra = 0; extra < 3; ++extra) {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (size_t)count * sizeof(f64) + ((size_t)4 << 30)) break;
+                void *spacer = NULL, *p2 = NULL;
+                const size_t sp = extra == 0 ? free_b / 8 : extra == 1 ? free_b / 3 : free_b / 8 * 5;
+                if (hipMalloc(&spacer, sp) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
+                if (hipMalloc(&p2, (size_t)count * sizeof(f64)) != hipSuccess) { (void)hipGetLastError(); p2 = NULL; }
+                if (spacer) HIPGUARD(hipFree(spacer));
+                if (!p2) break;
+                HIPGUARD(hipMemsetAsync(p2, 0, (size_t)count * sizeof(f64), s));
+                cand[n] = (f64*)p2;
+                pooled[n] = 0;
+                ++n;
+            }
+            if (n > 1) {
+                double keep_s = settled_s[1];
+                SETTLE(0, 1)
+                settled_s[1] += keep_s;
+                TIME_CANDIDATES(round2_ms)
+                round2_n = n;
+                for (int k = 1; k < n; ++k)
+                    if (round2_ms[k] < 0.99f * round2_ms[round2_pick]) round2_pick = k;
+                HIPGUARD(hipStreamSynchronize(s));
+                for (int k = 0; k < n; ++k)
+                    if (k != round2_pick) ws_vec_free_as(cand[k], pooled[k]);
+                keep_s = settled_s[1];
+                SETTLE(round2_pick, 1)
+                settled_s[1] += keep_s;
+            }
+            best = round2_pick;
+        }
+    }
 #undef SETTLE
 #undef TIME_CANDIDATES
 #undef TIME_CANDIDATE
     HIPGUARD(hipEventDestroy(a));
     HIPGUARD(hipEventDestroy(b));
     if (getenv("DFL_WS_VERBOSE")) {
-        fprintf(stderr, "[krylov] basis placement: settled after %.2f s at %.4f ms; in-loop SpMV into %d candidates:", settled_s[0], settled_ms[0], n);
-        for (int k = 0; k < n; ++k) fprintf(stderr, " %.4f%s%s", best_ms[k], pooled[k] ? "(pool)" : "", k == best_in_place ? "*" : "");
+        fprintf(stderr, "[krylov] basis placement: settled after %.2f s at %.4f ms; in-loop SpMV into %d candidates:", settled_s[0], settled_ms[0], n_round1);
+        for (int k = 0; k < n_round1; ++k) fprintf(stderr, " %.4f%s%s", best_ms[k], pooled1[k] ? "(pool)" : "", k == best_in_place ? "*" : "");
         fprintf(stderr, " ms\n");
         for (int v = 0; v < 2; ++v)
             if (moved_tested & (1 << v)) {
                 fprintf(stderr, "[krylov] value array on a %s heap copy:", v ? "far" : "plain");
-                for (int k = 0; k < n; ++k) fprintf(stderr, " %.4f", moved_ms[v][k]);
+                for (int k = 0; k < n_round1; ++k) fprintf(stderr, " %.4f", moved_ms[v][k]);
                 fprintf(stderr, " ms%s\n", moved == 1 + v ? " -> moved there" : "");
             }
-        fprintf(stderr, "[krylov] losers freed; settled after %.2f s at %.4f ms\n", settled_s[1], settled_ms[1]);
+        if (round2_n > 1) {
+            fprintf(stderr, "[krylov] second round, winner and %d new far blocks:", round2_n - 1);
+            for (int k = 0; k < round2_n; ++k) fprintf(stderr, " %.4f%s", round2_ms[k], k == round2_pick ? "*" : "");
+            fprintf(stderr, " ms\n");
+        }
+        fprintf(stderr, "[krylov] losers freed; settled after %.2f s in all at %.4f ms\n", settled_s[1], settled_ms[1]);
     }
     ex->q_pooled = pooled[best];
     return cand[best]; /* all-zero: only zero vectors went through the kernels above */
