@@ -529,7 +529,9 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     const int best_in_place = best;
     const int n_round1 = n;
     int pooled1[8];
-    for (int k = 0; k < 8; ++k) pooled1[k] = k < n ? pooled[k] : 0;
+    void* addr1[8];
+    for (int k = 0; k < 8; ++k) { pooled1[k] = k < n ? pooled[k] : 0; addr1[k] = k < n ? (void*)cand[k] : NULL; }
+    void* const addr_hv[2] = {hv[0], hv[1]};
     {
         float hv_best[2] = {1e30f, 1e30f};
         int hv_k[2] = {0, 0};
@@ -624,6 +626,9 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
             fprintf(stderr, " ms\n");
         }
         fprintf(stderr, "[krylov] losers freed; settled after %.2f s in all at %.4f ms\n", settled_s[1], settled_ms[1]);
+        fprintf(stderr, "[krylov] addresses: values %p (were %p; copies %p %p), first-round blocks", (void*)fs->block_val, (void*)old_val, addr_hv[0], addr_hv[1]);
+        for (int k = 0; k < n_round1; ++k) fprintf(stderr, " %p", addr1[k]);
+        fprintf(stderr, ", tmp %p, kept %p\n", (void*)ex->tmp, (void*)cand[best]);
     }
     ex->q_pooled = pooled[best];
     return cand[best]; /* all-zero: only zero vectors went through the kernels above */
