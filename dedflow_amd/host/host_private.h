@@ -146,10 +146,6 @@ void DflRangePush(const char* name);
 void DflRangePop(void);
 
 int DflDevicePoolEnabled(void); /* the default DEVICE allocator carves large requests out of its pool */
-/* the driver's "VRAM in use" figure (counts freed memory that is still being wiped), and a wait while it is falling
-   (host/runtime.c); -1 when rocm_smi is not available */
-int64_t DflDeviceMemoryInUse(void);
-double DflWaitDeviceMemoryQuiet(double max_seconds);
 
 void DflMatrixFSRelocateBlockValues(Matrix* m, value_type* new_val); /* host/matrix.c */
 

@@ -497,6 +497,14 @@ index_type DflTimeStep(Mesh3D* mesh, f64* wgold, f64* dwgold, f64* dwg, Matrix* 
 void DflMeshGeometryChanged(Mesh3D* mesh);
 /* device memory pool of the default DEVICE allocator (host/runtime.c; DFL_DEVICE_POOL_GB=0 disables it) */
 void DflDevicePoolStats(int64_t* reserved_bytes, int64_t* in_use_bytes);
+/* The driver wipes freed device memory in the background (~36 GB/s) and streaming kernels run up to 8 % slower meanwhile;
+ * hipMemGetInfo counts that memory as free at once.  DflDeviceMemoryInUse: the driver's own "VRAM in use" figure for the
+ * current device in bytes (it includes memory still to be wiped), -1 when rocm_smi is unavailable.  DflWaitDeviceMemoryQuiet:
+ * blocks while a wipe is in progress (that figure falling, or the SOC clock at its high level), at most max_seconds; returns
+ * the seconds waited, 0 when there was nothing to wait for, -1 when unknown.  Init() and the Krylov work-space calibration
+ * call it; a host program that frees tens of GB right before a timed region may want to as well (host/runtime.c). */
+int64_t DflDeviceMemoryInUse(void);
+double DflWaitDeviceMemoryQuiet(double max_seconds);
 /* boundary group whose faces get the weak-BC terms of AssembleSystemTetFace (default 4 = the reference's hard-coded group,
  * assemble.cu:1826-1828); lists are rebuilt when the group changes */
 void DflSetWeakBCGroup(index_type group);
