@@ -179,6 +179,9 @@ def main():
     t_total = time.perf_counter() - t0
     ms_per_step = 1e3 * t_total / args.steps
     solve_ms_timed = float(np.mean(solve_ms[-args.steps:]))
+    # what the Krylov work-space calibration measured and chose in the first warm-up solve ("SpMV placement":
+    # the in-loop SpMV time is a property of where the value array and the basis landed; this is the record of that draw)
+    placement_log = (L.DflKrylovCalibrationLog() or b"").decode(errors="replace").strip().split("\n")
     # separate, untimed pass with the profiler on: per-kernel durations for the roofline figures
     L.DflProfileEnable(1)
     n_prof_steps = min(args.steps, 20)   # the profiler holds 8192 intervals (~165 per step)
@@ -375,7 +378,7 @@ def main():
         "assemble_F_kernel_dofs_per_s": (6.0 * N / (tF * 1e-3)) if tF else None,
         "solve_to_rtol": to_rtol,
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "dem_sweep": dem,
-        "spmv_back_to_back_ms": spmv_grouped_ms, "coupled_step": coupled,
+        "spmv_back_to_back_ms": spmv_grouped_ms, "spmv_placement_calibration": placement_log, "coupled_step": coupled,
         # the whole Krylov solve against the HBM roofline: algorithmic bytes of its `its` matvecs (x0 = 0: r0 = b needs none),
         # its CGS steps, its+1 preconditioner applications and the final basis combination over the un-instrumented solve time
         "krylov_solve": (lambda b: {"ms": solve_ms_timed, "algorithmic_GB": b / 1e9, "GBps": b / (solve_ms_timed * 1e-3) / 1e9,

@@ -318,7 +318,7 @@ def _declare(L):
     f("DflTimeStep", i32, [C.POINTER(Mesh3D), vp, vp, vp, C.POINTER(Matrix), vp, vp, vp, vp, i32, i32, C.POINTER(ParticleContext),
                            i32, vp, vp])
     f("DflDevicePoolStats", None, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)])
-    f("DflDeviceMemoryInUse", C.c_int64, []); f("DflWaitDeviceMemoryQuiet", C.c_double, [C.c_double])
+    f("DflKrylovCalibrationLog", C.c_char_p, []); f("DflDeviceMemoryInUse", C.c_int64, []); f("DflWaitDeviceMemoryQuiet", C.c_double, [C.c_double])
     f("DflProfileEnable", None, [C.c_int]); f("DflProfileCollect", C.c_int, [C.c_int, C.POINTER(f64), C.POINTER(f64)])
     f("GenerateRandomColor", None, [vp, i32, i32])
     f("dfl_abi_version", C.c_int, [])

@@ -380,6 +380,9 @@ static void pc_apply_fused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64*
     else dfl_dcopy(na, w, z, DflStream());
 }
 
+static char g_cal_log[4096]; /* log of the most recent work-space calibration of this process */
+const char* DflKrylovCalibrationLog(void) { return g_cal_log; }
+
 /* Placement of the basis.  Measured (tools/probe_spmv_r2e.py, profiles/r02_spmv_workspace_candidates.txt): of six
  * identical 2.3 GB basis allocations made one after the other, the FIRST one (it reuses the address range the setup
  * temporaries were freed from) makes every SpMV of the Arnoldi loop that writes into it take 0.70 ms, the other five
@@ -496,12 +499,15 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     }
     /* the value array has a placement of its own: whole processes were measured in which the SpMV took 0.67 ms with the
        array where the allocator's pool put it, whatever the output vector, and 0.57 ms with a plain hipMalloc copy
-       (tools/probe_spmv_r2f.py).  So copies of the values are made -- a plain block, and one behind a spacer of a third of
-       the free memory -- BEFORE anything is timed (their spacer is the last big free), the same piece of the loop is timed
+       (tools/probe_spmv_r2f.py).  So copies of the values are made -- a plain block, and three behind spacers of a third, an
+       eighth and five eighths of the free memory (the value array's placement decides more than the basis block's: whole
+       rows of the candidate matrix are fast or slow) -- BEFORE anything is timed (their spacer is the last big free), the same piece of the loop is timed
        on them too, and the matrix moves if that is at least 3 % faster (DFL_VAL_RELOCATE=0 keeps it where it is). */
-    float moved_ms[2][8];
+    enum { NV = 4 }; /* value-array copies: a plain block, and blocks behind spacers of 1/3, 1/8 and 5/8 of the free memory */
+    static const char* const hv_name[NV] = {"plain", "far (1/3)", "far (1/8)", "far (5/8)"};
+    float moved_ms[NV][8];
     int moved = 0, moved_tested = 0;
-    void* hv[2] = {NULL, NULL};
+    void* hv[NV] = {NULL, NULL, NULL, NULL};
     MatrixFS* fs = (MatrixFS*)A->data;
     f64* const old_val = fs->block_val;
     {
@@ -509,12 +515,15 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
         size_t free_b = 0, total_b = 0;
         const char* ev = getenv("DFL_VAL_RELOCATE");
         if (!(ev && atoi(ev) == 0) && !fs->block_val_heap && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-            free_b > 3 * vbytes + ((size_t)4 << 30)) {
-            for (int v = 0; v < 2; ++v) {
+            free_b > (NV + 1) * vbytes + ((size_t)4 << 30)) {
+            for (int v = 0; v < NV; ++v) {
                 void* spacer = NULL;
-                if (v == 1) {
+                if (v >= 1) {
                     if (ncand < 5) continue; /* DFL_WS_CANDIDATES < 5: no far placements, no spacers */
-                    if (hipMalloc(&spacer, free_b / 3) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
+                    size_t fb = 0, tb = 0;
+                    if (hipMemGetInfo(&fb, &tb) != hipSuccess || fb < 2 * vbytes + ((size_t)4 << 30)) continue;
+                    const size_t sp = v == 1 ? fb / 3 : v == 2 ? fb / 8 : fb / 8 * 5;
+                    if (hipMalloc(&spacer, sp) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
                 }
                 if (hipMalloc(&hv[v], vbytes) != hipSuccess) { (void)hipGetLastError(); hv[v] = NULL; }
                 if (spacer) HIPGUARD(hipFree(spacer));
@@ -531,11 +540,11 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     int pooled1[8];
     void* addr1[8];
     for (int k = 0; k < 8; ++k) { pooled1[k] = k < n ? pooled[k] : 0; addr1[k] = k < n ? (void*)cand[k] : NULL; }
-    void* const addr_hv[2] = {hv[0], hv[1]};
+    void* const addr_hv[NV] = {hv[0], hv[1], hv[2], hv[3]};
     {
-        float hv_best[2] = {1e30f, 1e30f};
-        int hv_k[2] = {0, 0};
-        for (int v = 0; v < 2; ++v) {
+        float hv_best[NV] = {1e30f, 1e30f, 1e30f, 1e30f};
+        int hv_k[NV] = {0, 0, 0, 0};
+        for (int v = 0; v < NV; ++v) {
             if (!hv[v]) continue;
             fs->block_val = (f64*)hv[v]; /* timed in place of the original; nothing else runs meanwhile */
             TIME_CANDIDATES(moved_ms[v])
@@ -544,14 +553,16 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
             for (int k = 0; k < n; ++k)
                 if (moved_ms[v][k] < hv_best[v]) { hv_best[v] = moved_ms[v][k]; hv_k[v] = k; }
         }
-        const int vb = hv_best[1] < hv_best[0] ? 1 : 0;
+        int vb = 0;
+        for (int v = 1; v < NV; ++v)
+            if (hv_best[v] < hv_best[vb]) vb = v;
         if (hv[vb] && hv_best[vb] < 0.97f * best_ms[best]) {
             DflMatrixFSRelocateBlockValues(A, (f64*)hv[vb]);
             best = hv_k[vb];
             moved = 1 + vb;
             hv[vb] = NULL;
         }
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < NV; ++v)
             if (hv[v]) HIPGUARD(hipFree(hv[v]));
     }
     HIPGUARD(hipStreamSynchronize(s));
@@ -610,25 +621,31 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
 #undef TIME_CANDIDATE
     HIPGUARD(hipEventDestroy(a));
     HIPGUARD(hipEventDestroy(b));
-    if (getenv("DFL_WS_VERBOSE")) {
-        fprintf(stderr, "[krylov] basis placement: settled after %.2f s at %.4f ms; in-loop SpMV into %d candidates:", settled_s[0], settled_ms[0], n_round1);
-        for (int k = 0; k < n_round1; ++k) fprintf(stderr, " %.4f%s%s", best_ms[k], pooled1[k] ? "(pool)" : "", k == best_in_place ? "*" : "");
-        fprintf(stderr, " ms\n");
-        for (int v = 0; v < 2; ++v)
+    {   /* what was measured and decided: kept for DflKrylovCalibrationLog (bench.py records it), printed under DFL_WS_VERBOSE */
+        char* o = g_cal_log;
+        size_t left = sizeof g_cal_log;
+        g_cal_log[0] = 0;
+#define LOG(...) do { int w_ = snprintf(o, left, __VA_ARGS__); if (w_ > 0) { size_t u_ = (size_t)w_ < left ? (size_t)w_ : left - 1; o += u_; left -= u_; } } while (0)
+        LOG("[krylov] basis placement: settled after %.2f s at %.4f ms; in-loop SpMV into %d candidates:", settled_s[0], settled_ms[0], n_round1);
+        for (int k = 0; k < n_round1; ++k) LOG(" %.4f%s%s", best_ms[k], pooled1[k] ? "(pool)" : "", k == best_in_place ? "*" : "");
+        LOG(" ms\n");
+        for (int v = 0; v < NV; ++v)
             if (moved_tested & (1 << v)) {
-                fprintf(stderr, "[krylov] value array on a %s heap copy:", v ? "far" : "plain");
-                for (int k = 0; k < n_round1; ++k) fprintf(stderr, " %.4f", moved_ms[v][k]);
-                fprintf(stderr, " ms%s\n", moved == 1 + v ? " -> moved there" : "");
+                LOG("[krylov] value array on a %s heap copy:", hv_name[v]);
+                for (int k = 0; k < n_round1; ++k) LOG(" %.4f", moved_ms[v][k]);
+                LOG(" ms%s\n", moved == 1 + v ? " -> moved there" : "");
             }
         if (round2_n > 1) {
-            fprintf(stderr, "[krylov] second round, winner and %d new far blocks:", round2_n - 1);
-            for (int k = 0; k < round2_n; ++k) fprintf(stderr, " %.4f%s", round2_ms[k], k == round2_pick ? "*" : "");
-            fprintf(stderr, " ms\n");
+            LOG("[krylov] second round, winner and %d new far blocks:", round2_n - 1);
+            for (int k = 0; k < round2_n; ++k) LOG(" %.4f%s", round2_ms[k], k == round2_pick ? "*" : "");
+            LOG(" ms\n");
         }
-        fprintf(stderr, "[krylov] losers freed; settled after %.2f s in all at %.4f ms\n", settled_s[1], settled_ms[1]);
-        fprintf(stderr, "[krylov] addresses: values %p (were %p; copies %p %p), first-round blocks", (void*)fs->block_val, (void*)old_val, addr_hv[0], addr_hv[1]);
-        for (int k = 0; k < n_round1; ++k) fprintf(stderr, " %p", addr1[k]);
-        fprintf(stderr, ", tmp %p, kept %p\n", (void*)ex->tmp, (void*)cand[best]);
+        LOG("[krylov] losers freed; settled after %.2f s in all at %.4f ms\n", settled_s[1], settled_ms[1]);
+        LOG("[krylov] addresses: values %p (were %p; copies %p %p %p %p), first-round blocks", (void*)fs->block_val, (void*)old_val, addr_hv[0], addr_hv[1], addr_hv[2], addr_hv[3]);
+        for (int k = 0; k < n_round1; ++k) LOG(" %p", addr1[k]);
+        LOG(", tmp %p, kept %p\n", (void*)ex->tmp, (void*)cand[best]);
+#undef LOG
+        if (getenv("DFL_WS_VERBOSE")) fputs(g_cal_log, stderr);
     }
     ex->q_pooled = pooled[best];
     return cand[best]; /* all-zero: only zero vectors went through the kernels above */

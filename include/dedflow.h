@@ -504,6 +504,9 @@ void DflDevicePoolStats(int64_t* reserved_bytes, int64_t* in_use_bytes);
  * the seconds waited, 0 when there was nothing to wait for, -1 when unknown.  Init() and the Krylov work-space calibration
  * call it; a host program that frees tens of GB right before a timed region may want to as well (host/runtime.c). */
 int64_t DflDeviceMemoryInUse(void);
+/* text log of this process's most recent Krylov work-space calibration (host/solver.c: what every candidate placement
+ * measured, what was chosen, how long the waits were); "" when none has run.  DFL_WS_VERBOSE=1 prints the same to stderr. */
+const char* DflKrylovCalibrationLog(void);
 double DflWaitDeviceMemoryQuiet(double max_seconds);
 /* boundary group whose faces get the weak-BC terms of AssembleSystemTetFace (default 4 = the reference's hard-coded group,
  * assemble.cu:1826-1828); lists are rebuilt when the group changes */
