@@ -156,6 +156,15 @@ def main():
 
     solve_timer = api.Timer()
     solve_ms = []
+    quiet_waits = []
+
+    def quiet():
+        """Before a timed leg: wait while the driver is still wiping device memory that the set-up of that leg freed (DESIGN.md
+        section 3, 'SpMV placement': streaming kernels run up to 8 % slower in episodes meanwhile).  Returns at once when there is
+        nothing to wait for or rocm_smi is unavailable; the waits are reported in the JSON line."""
+        w = L.DflWaitDeviceMemoryQuiet(15.0)
+        if w > 0.0:
+            quiet_waits.append(round(w, 2))
 
     def step():
         P.assemble_system(wg_d, dwg_d, F_d, want_J=False)
@@ -170,6 +179,7 @@ def main():
     for _ in range(args.warmup):
         step()
     api.sync()
+    quiet()   # (a no-op after the calibration's own waits; see quiet())
     # timed region: EXACTLY --steps steps, no instrumentation inside (the in-library hipEvent profiler puts two
     # event packets around every kernel, which costs bubbles and stops consecutive kernels from overlapping)
     t0 = time.perf_counter()
@@ -270,7 +280,7 @@ def main():
         res = []
         for rep in range(2):              # the first solve builds the DILU coloring and grows the basis
             x_d.zero()
-            api.sync(); tw = time.perf_counter()
+            api.sync(); quiet(); tw = time.perf_counter()
             it2, r02, hist2, conv2 = P.solve(x_d, F_d)
             api.sync(); res.append(time.perf_counter() - tw)
         to_rtol = {"pc": "PC_ILU0 (multicolor block-DILU)", "rtol": 1e-4, "iterations": it2, "converged": bool(conv2),
@@ -282,7 +292,7 @@ def main():
         res = []
         for rep in range(2):              # the first solve builds the aggregates and the coarse matrix
             x_d.zero()
-            api.sync(); tw = time.perf_counter()
+            api.sync(); quiet(); tw = time.perf_counter()
             it3, r03, hist3, conv3 = P.solve(x_d, F_d)
             api.sync(); res.append(time.perf_counter() - tw)
         to_rtol["twolevel"] = {"pc": "PC_TWOLEVEL (block-DILU smoother + aggregation coarse level, FGMRES)", "iterations": it3,
@@ -302,6 +312,7 @@ def main():
         pc = api.Particles(xp, vp_, R)
         pc.compute_forces()
         api.sync()
+        quiet()
         nrep = 50
         tw = time.perf_counter()          # un-instrumented: the in-library profiler puts two event packets around the force
         for _ in range(nrep):             # kernel, which is a visible share of a 50 us sweep
@@ -344,6 +355,7 @@ def main():
         substeps, newton = 10, 2
         P4.time_step(st[0], st[1], st[2], F4, dx4, newton_maxit=newton, particles=pc4, dem_substeps=substeps)
         api.sync()
+        quiet()
         tw = time.perf_counter()
         nrep = 3
         its4 = 0
@@ -378,7 +390,7 @@ def main():
         "assemble_F_kernel_dofs_per_s": (6.0 * N / (tF * 1e-3)) if tF else None,
         "solve_to_rtol": to_rtol,
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "dem_sweep": dem,
-        "spmv_back_to_back_ms": spmv_grouped_ms, "spmv_placement_calibration": placement_log, "coupled_step": coupled,
+        "spmv_back_to_back_ms": spmv_grouped_ms, "spmv_placement_calibration": placement_log, "waits_for_driver_memory_wipe_s": quiet_waits, "coupled_step": coupled,
         # the whole Krylov solve against the HBM roofline: algorithmic bytes of its `its` matvecs (x0 = 0: r0 = b needs none),
         # its CGS steps, its+1 preconditioner applications and the final basis combination over the un-instrumented solve time
         "krylov_solve": (lambda b: {"ms": solve_ms_timed, "algorithmic_GB": b / 1e9, "GBps": b / (solve_ms_timed * 1e-3) / 1e9,
