@@ -1,7 +1,7 @@
 """Probe: compute time of ONE rank's share of the 10M-tet step at an 8-way partition (rank 0's local mesh incl. its halo
 layer), run through the partitioned code path (owned rows, interior/boundary split, RCCL communicator of world size 1 with
 an empty halo plan).  No inter-GPU latency is in it: t_1gpu / this = the ceiling of the 8-GPU strong-scaling factor.
-Launch: python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 tools/probe_rank_local.py [M] [parts]"""
+Launch: python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 tools/probe_rank_local.py [M] [parts] [slot-patch leaf]"""
 import sys, os, time, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +11,8 @@ from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 119
 parts = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+if len(sys.argv) > 3:   # J-assembly patch size (nodes per slot-owner patch), default 7
+    api.lib().DflSetSlotPatchParameters(int(sys.argv[3]), 200, 128)
 its = 40
 torch.cuda.set_device(0)
 device = torch.device("cuda", 0)
