@@ -499,15 +499,15 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     }
     /* the value array has a placement of its own: whole processes were measured in which the SpMV took 0.67 ms with the
        array where the allocator's pool put it, whatever the output vector, and 0.57 ms with a plain hipMalloc copy
-       (tools/probe_spmv_r2f.py).  So copies of the values are made -- a plain block, and three behind spacers of a third, an
-       eighth and five eighths of the free memory (the value array's placement decides more than the basis block's: whole
+       (tools/probe_spmv_r2f.py).  So copies of the values are made -- a plain block, and five behind spacers of between an eighth and
+       five eighths of the free memory (the value array's placement decides more than the basis block's: whole
        rows of the candidate matrix are fast or slow) -- BEFORE anything is timed (their spacer is the last big free), the same piece of the loop is timed
        on them too, and the matrix moves if that is at least 3 % faster (DFL_VAL_RELOCATE=0 keeps it where it is). */
-    enum { NV = 4 }; /* value-array copies: a plain block, and blocks behind spacers of 1/3, 1/8 and 5/8 of the free memory */
-    static const char* const hv_name[NV] = {"plain", "far (1/3)", "far (1/8)", "far (5/8)"};
+    enum { NV = 6 }; /* value-array copies: a plain block, and blocks behind spacers of 1/3, 1/8, 5/8, 1/4 and 1/2 of the free memory */
+    static const char* const hv_name[NV] = {"plain", "far (1/3)", "far (1/8)", "far (5/8)", "far (1/4)", "far (1/2)"};
     float moved_ms[NV][8];
     int moved = 0, moved_tested = 0;
-    void* hv[NV] = {NULL, NULL, NULL, NULL};
+    void* hv[NV] = {NULL, NULL, NULL, NULL, NULL, NULL};
     MatrixFS* fs = (MatrixFS*)A->data;
     f64* const old_val = fs->block_val;
     {
@@ -522,7 +522,7 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
                     if (ncand < 5) continue; /* DFL_WS_CANDIDATES < 5: no far placements, no spacers */
                     size_t fb = 0, tb = 0;
                     if (hipMemGetInfo(&fb, &tb) != hipSuccess || fb < 2 * vbytes + ((size_t)4 << 30)) continue;
-                    const size_t sp = v == 1 ? fb / 3 : v == 2 ? fb / 8 : fb / 8 * 5;
+                    const size_t sp = v == 1 ? fb / 3 : v == 2 ? fb / 8 : v == 3 ? fb / 8 * 5 : v == 4 ? fb / 4 : fb / 2;
                     if (hipMalloc(&spacer, sp) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
                 }
                 if (hipMalloc(&hv[v], vbytes) != hipSuccess) { (void)hipGetLastError(); hv[v] = NULL; }
@@ -540,10 +540,10 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
     int pooled1[8];
     void* addr1[8];
     for (int k = 0; k < 8; ++k) { pooled1[k] = k < n ? pooled[k] : 0; addr1[k] = k < n ? (void*)cand[k] : NULL; }
-    void* const addr_hv[NV] = {hv[0], hv[1], hv[2], hv[3]};
+    void* const addr_hv[NV] = {hv[0], hv[1], hv[2], hv[3], hv[4], hv[5]};
     {
-        float hv_best[NV] = {1e30f, 1e30f, 1e30f, 1e30f};
-        int hv_k[NV] = {0, 0, 0, 0};
+        float hv_best[NV] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+        int hv_k[NV] = {0, 0, 0, 0, 0, 0};
         for (int v = 0; v < NV; ++v) {
             if (!hv[v]) continue;
             fs->block_val = (f64*)hv[v]; /* timed in place of the original; nothing else runs meanwhile */
@@ -641,7 +641,8 @@ static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_
             LOG(" ms\n");
         }
         LOG("[krylov] losers freed; settled after %.2f s in all at %.4f ms\n", settled_s[1], settled_ms[1]);
-        LOG("[krylov] addresses: values %p (were %p; copies %p %p %p %p), first-round blocks", (void*)fs->block_val, (void*)old_val, addr_hv[0], addr_hv[1], addr_hv[2], addr_hv[3]);
+        LOG("[krylov] addresses: values %p (were %p; copies %p %p %p %p %p %p), first-round blocks", (void*)fs->block_val, (void*)old_val, addr_hv[0], addr_hv[1], addr_hv[2],
+            addr_hv[3], addr_hv[4], addr_hv[5]);
         for (int k = 0; k < n_round1; ++k) LOG(" %p", addr1[k]);
         LOG(", tmp %p, kept %p\n", (void*)ex->tmp, (void*)cand[best]);
 #undef LOG
