@@ -30,7 +30,7 @@ $(H5LIB): dedflow_amd/h5/h5io.c include/dedflow.h $(LIB)
 dedflow_amd/csrc/%.o: dedflow_amd/csrc/%.hip dedflow_amd/csrc/dfl_common.hpp dedflow_amd/csrc/asm_device.hpp include/dedflow_kernels.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-dedflow_amd/host/%.o: dedflow_amd/host/%.c include/dedflow.h include/dedflow_kernels.h dedflow_amd/host/host_private.h dedflow_amd/host/rcb.h
+dedflow_amd/host/%.o: dedflow_amd/host/%.c include/dedflow.h include/dedflow_kernels.h dedflow_amd/host/host_private.h dedflow_amd/host/solver_private.h dedflow_amd/host/rcb.h
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(LIB): $(KOBJ) $(HOBJ)
@@ -43,7 +43,7 @@ oracle:
 # not available on this pool; sanitizers run on the CPU-only tests: tools/run_cpu_sanitized.sh)
 SANLIB  = dedflow_amd/libdedflow_asan.so
 SANOBJ  = $(HSRC:.c=.san.o)
-dedflow_amd/host/%.san.o: dedflow_amd/host/%.c include/dedflow.h include/dedflow_kernels.h dedflow_amd/host/host_private.h dedflow_amd/host/rcb.h
+dedflow_amd/host/%.san.o: dedflow_amd/host/%.c include/dedflow.h include/dedflow_kernels.h dedflow_amd/host/host_private.h dedflow_amd/host/solver_private.h dedflow_amd/host/rcb.h
 	$(CC) $(CFLAGS) -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -c $< -o $@
 $(SANLIB): $(KOBJ) $(SANOBJ)
 	$(HIPCC) -shared -fPIC -fopenmp --offload-arch=$(ARCH) -fsanitize=address,undefined -o $@ $^ || \

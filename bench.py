@@ -52,51 +52,85 @@ def algorithmic_bytes(N, T, nnz1, its):
     }
 
 
-def cpu_baseline(M_sample, its):
-    """The CPU oracle (oracle/liboracle.so, single thread, kind "port") on a bounded sample
-    of the same step: same mesh family, smaller M.  Test infrastructure used as the
-    reported baseline only -- never on the product path."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(M_full, M_single, its):
+    """The CPU oracle (oracle/liboracle.so, kind "port") timed on this box's host cores, two legs:
+      * all host threads of this rank's share (<= 16) on the SAME mesh as the GPU line (M_full; about 10-30 s of CPU work),
+      * one thread on a smaller mesh of the same family (M_single), with a scipy.sparse CSR matvec on that matrix as an
+        independent SpMV yardstick.
+    Test infrastructure used as the reported baseline only -- never on the product path."""
     from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
     from oracle import orc
-    m = kuhn_cube(M_sample, jitter=0.2)
-    wg, dwg = synthetic_fields(m)
-    S = orc.System(m)
-    spmv_bytes = 132.0 * S.nnz1 + 4.0 * (S.N + 1) + 64.0 * S.N
-    x = np.random.default_rng(0).normal(size=6 * S.N)
 
-    def leg(threads):
+    def leg(S, wg, dwg, threads, reps_spmv=3):
         orc.set_threads(threads)
+        spmv_bytes = 132.0 * S.nnz1 + 4.0 * (S.N + 1) + 64.0 * S.N
+        x = np.random.default_rng(0).normal(size=6 * S.N)
         t0 = time.perf_counter()
         F, _ = S.assemble_system(wg, dwg, True, False)
         tF = time.perf_counter() - t0
         t0 = time.perf_counter()
         _, vals = S.assemble_system(wg, dwg, False, True)
         tJ = time.perf_counter() - t0
+        S.matvec(vals, x)
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(reps_spmv):
             S.matvec(vals, x)
-        tS = (time.perf_counter() - t0) / 5
+        tS = (time.perf_counter() - t0) / reps_spmv
         t0 = time.perf_counter()
         S.gmres(vals, F, maxit=its, atol=0.0, rtol=0.0)
         tG = time.perf_counter() - t0
         step = tF + tJ + tG
-        return {"value": 4.0 * S.N / step, "cores": threads, "assemble_J_s": tJ, "assemble_F_s": tF, "gmres_s": tG, "spmv_s": tS,
-                "assemble_J_dofs_per_s": 4.0 * S.N / tJ, "spmv_GBps": spmv_bytes / tS / 1e9}
+        return ({"value": 4.0 * S.N / step, "cores": threads, "assemble_J_s": tJ, "assemble_F_s": tF, "gmres_s": tG, "spmv_s": tS,
+                 "assemble_J_dofs_per_s": 4.0 * S.N / tJ, "spmv_GBps": spmv_bytes / tS / 1e9}, vals, x)
 
-    # all host cores of this rank's share (OpenMP over elements-within-color / rows / fixed dot chunks; the
-    # results do not depend on the thread count) and, for reference, one thread
     ncores = max(1, min(orc.num_procs(), 16))
-    multi = leg(ncores)
-    single = leg(1) if ncores > 1 else dict(multi)
-    orc.set_threads(1)
+    t_set = time.perf_counter()
+    m = kuhn_cube(M_full, jitter=0.2)
+    wg, dwg = synthetic_fields(m)
+    orc.set_threads(ncores)
+    S = orc.System(m, sorted_coloring=True)   # one-pass form of the JPL coloring: same colors (tests/test_oracle_cpu.py)
+    t_set = time.perf_counter() - t_set
+    multi, vals, x = leg(S, wg, dwg, ncores)
     out = dict(multi)
     out.update({
-        "unit": "DOF/s", "kind": "port",
-        "sample": f"SMALLER mesh than the GPU line: Kuhn cube M={M_sample} ({S.T} tets, {S.N} nodes), same step (F + J "
-                  f"assembly, {its} GMRES its), oracle/liboracle.so with OpenMP on {ncores} host threads; `value` is DOF/s "
-                  f"of that sample, i.e. a per-DOF rate to be read against the 10M-tet GPU line as an extrapolation",
-        "single_thread": single,
+        "unit": "DOF/s", "kind": "port", "cpu_model": cpu_model(), "host_threads_available": orc.num_procs(),
+        "sample": f"the GPU line's own mesh: Kuhn cube M={M_full} ({S.T} tets, {S.N} nodes), same step (F + J assembly, {its} GMRES "
+                  f"its), oracle/liboracle.so with OpenMP on {ncores} host threads (set-up {t_set:.0f} s, not in `value`)",
     })
+    del S, vals, x, m, wg, dwg
+    single = None
+    if M_single > 0:
+        m1 = kuhn_cube(M_single, jitter=0.2)
+        w1, d1 = synthetic_fields(m1)
+        S1 = orc.System(m1, sorted_coloring=True)
+        single, vals1, x1 = leg(S1, w1, d1, 1)
+        single["sample"] = f"SMALLER mesh: Kuhn cube M={M_single} ({S1.T} tets, {S1.N} nodes), one thread"
+        try:   # independent SpMV yardstick: scipy.sparse CSR (one thread) on the same 4N x 4N matrix
+            A = S1.to_scipy(vals1)
+            xs = x1[:4 * S1.N].copy()
+            A @ xs
+            t0 = time.perf_counter()
+            for _ in range(3):
+                A @ xs
+            ts = (time.perf_counter() - t0) / 3
+            single["scipy_csr_spmv_s"] = ts
+            single["scipy_csr_spmv_GBps"] = (132.0 * S1.nnz1 + 4.0 * (S1.N + 1) + 64.0 * S1.N) / ts / 1e9
+            single["scipy_csr_bytes_actually_streamed"] = 12.0 * A.nnz + 4.0 * (4 * S1.N + 1) + 64.0 * S1.N
+        except Exception as exc:  # noqa: BLE001
+            single["scipy_csr_spmv_s"] = None
+            single["scipy_error"] = repr(exc)
+    orc.set_threads(1)
+    out["single_thread"] = single
     return out
 
 
@@ -107,7 +141,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--M", type=int, default=119, help="cells per cube edge (119 -> 10.1M tets)")
     ap.add_argument("--gmres-its", type=int, default=40)
-    ap.add_argument("--cpu-M", type=int, default=64, help="cube size of the CPU-baseline sample (0 = skip); 64 = 1.57M tets, ~10-15 s of CPU work")
+    ap.add_argument("--cpu-M", type=int, default=-1, help="cube size of the multi-thread CPU-baseline leg (-1 = the GPU line's M, 0 = skip)")
+    ap.add_argument("--cpu-single-M", type=int, default=64, help="cube size of the single-thread CPU leg + scipy yardstick (0 = skip)")
+    ap.add_argument("--placement", choices=["calibrate", "default", "off"], default="calibrate",
+                    help="Krylov work-space placement: explicit heavy DflKrylovCalibratePlacement before the warm-up (calibrate), the "
+                         "library's bounded default, or none")
+    ap.add_argument("--placement-cap-gb", type=float, default=0.0, help="transient device memory the explicit calibration may hold (0 = no cap)")
     ap.add_argument("--jitter", type=float, default=0.2)
     ap.add_argument("--solve-to-rtol", type=int, default=1, help="also time one PC_ILU0 solve to rtol 1e-4 after the timed steps (0 = skip)")
     ap.add_argument("--coupled-M", type=int, default=55, help="fluid mesh of the coupled fluid + DEM step leg (0 = skip)")
@@ -176,6 +215,21 @@ def main():
         solve_ms.append(solve_timer.ms())
         return out
 
+    # Krylov work-space placement: the library's default is a bounded pick among <= 4 basis blocks inside
+    # the first solve; the heavy lottery (spacers, value-array copies, waits for the driver's wipe) is this explicit call,
+    # made BEFORE the warm-up and named in `config.placement`
+    L.DflKrylovCalibratePlacement.argtypes = [C.c_void_p, C.POINTER(api.Matrix), C.c_int64]
+    L.DflKrylovCalibratePlacement.restype = None
+    t_cal = 0.0
+    if args.placement == "off":
+        os.environ["DFL_WS_CANDIDATES"] = "1"
+    elif args.placement == "calibrate":
+        P.assemble_system(wg_d, dwg_d, None, want_J=True)
+        api.sync()
+        t_cal = time.perf_counter()
+        L.DflKrylovCalibratePlacement(P.ksp, P.J, int(args.placement_cap_gb * 2 ** 30))
+        api.sync()
+        t_cal = time.perf_counter() - t_cal
     for _ in range(args.warmup):
         step()
     api.sync()
@@ -231,10 +285,8 @@ def main():
     c, t, _ = prof["asm_lhs"]; entry("asm_lhs", ab["asm_lhs"] * K, c, t, "128*nnz1+16*T+120N per J assembly = SURVEY 8(d) compulsory floor "
                                                                       "(slot-owner node patches, ONE launch, no atomics; the "
                                                                       "colored scatter of SURVEY 8(d) would move 4116*T+120N)")
-    if "asm_lhs" in kernels:  # the same time against the bytes the reference-shaped colored scatter would move
-        eq = ab["asm_lhs_colored"] * K / (prof["asm_lhs"][1] * 1e-3) / 1e9
-        kernels["asm_lhs"].update({"colored_scatter_bytes_per_assembly": ab["asm_lhs_colored"],
-                                   "GBps_equivalent_colored_scatter": eq, "frac_of_8TBps_equivalent_colored_scatter": eq / HBM_PEAK_GBS})
+    if "asm_lhs" in kernels:  # what the reference-shaped colored scatter would move, for orientation only
+        kernels["asm_lhs"]["colored_scatter_bytes_per_assembly"] = ab["asm_lhs_colored"]
     c, t, _ = prof["asm_rhs"]; entry("asm_rhs", ab["asm_rhs"] * K, c, t, "404*T+120N per F assembly = the colored-scatter byte model (lane-per-tet persistent wave kernel + ordered node sum: 2 launches; PMC traffic: roofline.traffic / profiles/pmc_traffic_M119.json)")
     c, t, _ = prof["pc_apply"]; entry("pc_apply", ab["pc_apply"] * c, c, t, "80N+64N per apply")
     cd, td, _ = prof["cgs_dots"]; cu, tu, _ = prof["cgs_update"]
@@ -253,6 +305,15 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_M119.json")))
             if dominant in pmc:
                 traffic = pmc[dominant]["hbm_bytes_per_launch"]
+            # every kernel with a committed PMC figure also gets its rate against the bytes it really moved
+            for name, kk in kernels.items():
+                names = {"asm_rhs": ["asm_rhs", "rhs_node_sum"]}.get(name, [name])
+                if all(nm in pmc for nm in names) and kk["launches"]:
+                    tb = sum(pmc[nm]["hbm_bytes_per_launch"] for nm in names)
+                    per_unit_ms = kk["total_ms_per_step"] if name in ("asm_lhs", "asm_rhs") else kk["avg_ms"]
+                    kk["pmc_traffic_bytes"] = tb
+                    kk["GBps_vs_pmc_traffic"] = tb / (per_unit_ms * 1e-3) / 1e9
+                    kk["frac_of_8TBps_vs_pmc_traffic"] = kk["GBps_vs_pmc_traffic"] / HBM_PEAK_GBS
     except Exception:
         traffic = None
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": kd["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -302,7 +363,8 @@ def main():
         ksp_i[0] = its
         ksp_f[1], ksp_f[2] = 0.0, 0.0
 
-    cpu = cpu_baseline(args.cpu_M, its) if args.cpu_M > 0 else None
+    cpu_M = args.M if args.cpu_M < 0 else args.cpu_M
+    cpu = cpu_baseline(cpu_M, args.cpu_single_M, its) if cpu_M > 0 else None
 
     # ---- DEM contact sweep (BASELINE config 4 inputs: P = 100k, R = 0.004), outside the timed step ------------
     dem = None
@@ -327,7 +389,7 @@ def main():
         cnt = L.DflProfileCollect(9, C.byref(tot), C.byref(mn))
         L.DflProfileEnable(0)
         kbar = None
-        if args.cpu_M > 0:  # mean neighbours actually tested, from the CPU oracle's cell list (same inputs)
+        if cpu_M > 0:  # mean neighbours actually tested, from the CPU oracle's cell list (same inputs)
             from oracle import orc
             _, tested = orc.dem_forces(xp, vp_, R)
             kbar = tested / float(args.dem_particles)
@@ -380,7 +442,11 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"Kuhn cube M={args.M}: {T} tets, {N} nodes, nnz1={nnz1}; step = AssembleSystem(F) + "
                                f"AssembleSystem(J) + Jacobi-PC GMRES x{its} iterations",
-                   "colors": P.num_color, "gmres_its": its, "parallelism": "1 GPU"},
+                   "colors": P.num_color, "gmres_its": its, "parallelism": "1 GPU",
+                   "placement": {"calibrate": f"explicit DflKrylovCalibratePlacement before the warm-up ({t_cal:.1f} s, cap "
+                                              f"{args.placement_cap_gb or 'none'} GB): basis blocks + value-array copies behind spacers",
+                                 "default": "library default: bounded pick among <= 4 basis blocks in the first solve",
+                                 "off": "none (DFL_WS_CANDIDATES=1)"}[args.placement]},
         "spmv_GBps": kernels.get("spmv", {}).get("GBps"), "spmv_frac_of_hbm_peak": kernels.get("spmv", {}).get("frac_of_8TBps"),
         # whole AssembleSystem calls (pack + element kernels + faces + Dirichlet), event-timed; the element kernels alone
         # are in `kernels` (asm_lhs / asm_rhs)

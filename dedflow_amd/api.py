@@ -245,11 +245,13 @@ class Particles:
 PC_DECOMPOSITION, PC_ILU0, PC_TWOLEVEL = 0x2, 0x5, 0x6   # PCType values (include/dedflow.h)
 ALLREDUCE_FN = C.CFUNCTYPE(None, vp, vp, C.c_int32)
 HALO_FN = C.CFUNCTYPE(None, vp, vp)
+STREAM_FN = C.CFUNCTYPE(vp, vp)
 
 
 class DflComm(C.Structure):
     _fields_ = [("allreduce_sum", ALLREDUCE_FN), ("halo_exchange", HALO_FN), ("ctx", vp), ("num_owned_node", C.c_int32),
-                ("halo_begin", HALO_FN), ("halo_end", HALO_FN), ("num_interior_node", C.c_int32)]
+                ("halo_begin", HALO_FN), ("halo_end", HALO_FN), ("num_interior_node", C.c_int32),
+                ("rank", C.c_int), ("world", C.c_int), ("halo_stream", STREAM_FN)]
 
 
 def _declare(L):

@@ -41,11 +41,11 @@ __global__ __launch_bounds__(BLK) void restrict_kernel(I Nc, const I* __restrict
     if (g == 0) rc[c < 3 ? 3 * w + c : 3LL * Nc + w] = acc;
 }
 
-// z += P xc: every node adds the correction of its aggregate
-__global__ __launch_bounds__(BLK) void prolong_add_kernel(I N, const I* __restrict__ agg, I Nc, const T* __restrict__ xc,
+// z += P xc: every node of rows [0, nrows) adds the correction of its aggregate (partitioned runs: the owned nodes)
+__global__ __launch_bounds__(BLK) void prolong_add_kernel(I nrows, I N, const I* __restrict__ agg, I Nc, const T* __restrict__ xc,
                                                          T* __restrict__ z) {
     const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
-    if (i >= N) return;
+    if (i >= nrows) return;
     const long long a = agg[i];
     z[3 * i] += xc[3 * a];
     z[3 * i + 1] += xc[3 * a + 1];
@@ -67,10 +67,13 @@ void dfl_amg_restrict(I Nc, const I* aoff, const I* anode, I N, const T* r, T* r
     restrict_kernel<<<ceil_div((long long)Nc * 64, BLK), BLK, 0, S(stream)>>>(Nc, aoff, anode, N, r, rc);
     DFL_LAUNCH_CHECK();
 }
-void dfl_amg_prolong_add(I N, const I* agg, I Nc, const T* xc, T* z, void* stream) {
-    if (N <= 0) return;
-    prolong_add_kernel<<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, agg, Nc, xc, z);
+void dfl_amg_prolong_add_rows(I nrows, I N, const I* agg, I Nc, const T* xc, T* z, void* stream) {
+    if (nrows <= 0) return;
+    prolong_add_kernel<<<ceil_div(nrows, BLK), BLK, 0, S(stream)>>>(nrows, N, agg, Nc, xc, z);
     DFL_LAUNCH_CHECK();
+}
+void dfl_amg_prolong_add(I N, const I* agg, I Nc, const T* xc, T* z, void* stream) {
+    dfl_amg_prolong_add_rows(N, N, agg, Nc, xc, z, stream);
 }
 
 }  // extern "C"

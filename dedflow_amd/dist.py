@@ -309,7 +309,8 @@ class DistSolverComm:
 
         self._a, self._h = api.ALLREDUCE_FN(_allreduce), api.HALO_FN(_halo)
         # no split exchange on this path (synchronous callbacks); the interior / boundary row split is still used
-        self.comm = api.DflComm(self._a, self._h, None, plan.n_owned, api.HALO_FN(), api.HALO_FN(), plan.n_interior)
+        self.comm = api.DflComm(self._a, self._h, None, plan.n_owned, api.HALO_FN(), api.HALO_FN(), plan.n_interior,
+                                plan.rank, plan.world, api.STREAM_FN())
 
     def install(self, ksp):
         from . import api
@@ -335,8 +336,15 @@ class RcclSolverComm:
         L.DflRcclCommVtable.restype, L.DflRcclCommVtable.argtypes = vp, [vp]
         L.DflRcclCommCounters.restype, L.DflRcclCommCounters.argtypes = None, [vp, vp, vp]
         L.DflRcclCommDestroy.restype, L.DflRcclCommDestroy.argtypes = None, [vp]
-        # Every rank walks the same sequence of collectives whatever fails locally (a rank that raised before a collective
-        # the others entered would leave them waiting): local failures are recorded in `ok` and agreed on at the end.
+        # ncclCommInitRank is itself a rendezvous: a rank that skipped it would leave the others waiting inside it.  So every
+        # local precondition (library loaded, ids made and received) is agreed on with a MIN all-reduce over torch.distributed
+        # BEFORE anybody enters it, the outcome of each ncclCommInitRank is agreed on right after it, and all ranks take the
+        # same branch: either every rank holds both communicators, or every rank raises here.
+        def agree(ok_local):
+            flag = torch.tensor([1.0 if ok_local else 0.0], dtype=torch.float64, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item() > 0.5)
+
         bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         path = bundled if os.path.exists(bundled) else ""     # the RCCL build torch already runs on
         ok, why = True, ""
@@ -355,21 +363,23 @@ class RcclSolverComm:
         dist.broadcast_object_list(box, src=0)
         torch.cuda.synchronize()
         self.c = None
-        if ok and len(box[0]) == nbytes and len(box[1]) == nbytes:   # rank 0 had no id: nobody creates a communicator
-            self.c = L.DflRcclCommCreate(box[0], plan.rank, plan.world)
-            if not self.c:
-                ok, why = False, "DflRcclCommCreate failed"
-        else:
-            ok, why = False, why or "rank 0 could not create the RCCL unique ids"
-        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if flag.item() < 0.5:
+        if ok and not (len(box[0]) == nbytes and len(box[1]) == nbytes):
+            ok, why = False, "rank 0 could not create the RCCL unique ids"
+        if not agree(ok):                                       # nobody has entered ncclCommInitRank yet
+            raise RuntimeError(why or "RCCL is unavailable on another rank")
+        self.c = L.DflRcclCommCreate(box[0], plan.rank, plan.world)
+        if not agree(bool(self.c)):
             if self.c:
                 L.DflRcclCommDestroy(self.c)
                 self.c = None
-            raise RuntimeError(why or "the RCCL communicator failed on another rank")   # raised on EVERY rank
-        L.DflRcclCommCreateHaloComm.restype, L.DflRcclCommCreateHaloComm.argtypes = None, [vp, C.c_char_p]
-        L.DflRcclCommCreateHaloComm(self.c, box[1])
+            raise RuntimeError("ncclCommInitRank failed on this or another rank")   # raised on EVERY rank
+        L.DflRcclCommCreateHaloComm.restype, L.DflRcclCommCreateHaloComm.argtypes = C.c_int, [vp, C.c_char_p]
+        L.DflRcclCommDropHaloComm.restype, L.DflRcclCommDropHaloComm.argtypes = None, [vp]
+        halo_ok = L.DflRcclCommCreateHaloComm(self.c, box[1]) == 0
+        if not agree(halo_ok):
+            # one rank sharing the main communicator for its halo traffic while its peers use a second one would pair
+            # sends and receives of different communicators: every rank drops the second communicator
+            L.DflRcclCommDropHaloComm(self.c)
         sc = np.asarray(plan.send_splits, np.int32)
         rc = np.asarray(plan.recv_splits, np.int32)
         si = np.ascontiguousarray(plan.send_all.cpu().numpy().astype(np.int32))

@@ -61,14 +61,25 @@ void DflMeshGeometryChanged(Mesh3D* mesh) {
 }
 b32 DflQuiet(void) { return g_quiet; }
 
-static const CSRAttr* block_pattern(Matrix* J, value_type** val) {
+/* the 4x4-block array the kernels write and its nodal pattern.  Block mode: the matrix's own storage.  Reference layout
+ * (MatrixFSUseReferenceLayout): a scratch block array filled from the four sub-matrix arrays, written back by block_done --
+ * *scratch says which.  Anything else is not the (u,p) matrix of main.c:374-391: message + trap, as the reference's guards. */
+static const CSRAttr* block_pattern(Matrix* J, value_type** val, b32* scratch) {
     *val = MatrixFSBlockValues(J);
+    *scratch = FALSE;
+    if (!*val) {
+        *val = DflMatrixFSScratchBlockBegin(J);
+        *scratch = *val != NULL;
+    }
     if (!*val) {
         fprintf(stderr, "AssembleSystemTet: J must be the (u,p) field-split matrix of src/main.c:374-391 after MatrixSetup\n");
         ASSERT(FALSE);
         return NULL;
     }
     return ((MatrixFS*)J->data)->spy1x1;
+}
+static void block_done(Matrix* J, b32 scratch) {
+    if (scratch) DflMatrixFSScratchBlockEnd(J);
 }
 
 /* (elem,a,b) -> nonzero map for this pattern, batch order; built once per (mesh, pattern) */
@@ -91,6 +102,33 @@ f64* DflMeshNodeRecords(Mesh3D* mesh) {
     return x->nodep;
 }
 
+/* The Jacobian schedule of this mesh for this pattern (modes 2-4), built on first use.  A builder that refuses the mesh --
+ * it has printed why: a node patch beyond the kernel's slot / tet limits, too many patch colors -- makes the mesh FALL BACK
+ * to schedule 1 (compact colors, the reference-shaped scatter) for good instead of trapping.  Returns the mode in force. */
+static int ensure_lhs_schedule(Mesh3D* mesh, const CSRAttr* spy) {
+    MeshExt* x = (MeshExt*)mesh->ext;
+    const int mode = x->cfg.sched_mode;
+    b32 failed = FALSE;
+    if (mode == 2) {
+        if (x->patch && x->patch->attr != spy) { DflFreePatchSchedule(x->patch); x->patch = NULL; }
+        if (!x->patch) x->patch = DflBuildPatchSchedule(mesh, spy, x->cfg.patch_leaf, x->cfg.patch_cap);
+        failed = x->patch == NULL;
+    } else if (mode == 3) {
+        if (x->rowpatch && x->rowpatch->attr != spy) { DflFreeRowPatchSchedule(x->rowpatch); x->rowpatch = NULL; }
+        if (!x->rowpatch) x->rowpatch = DflBuildRowPatchSchedule(mesh, spy, x->cfg.rowpatch_leaf, x->cfg.rowpatch_cap);
+        failed = x->rowpatch == NULL;
+    } else if (mode == 4) {
+        if (x->slotpatch && x->slotpatch->attr != spy) { DflFreeSlotPatchSchedule(x->slotpatch); x->slotpatch = NULL; }
+        if (!x->slotpatch) x->slotpatch = DflBuildSlotPatchSchedule(mesh, spy, x->cfg.slot_leaf, x->cfg.slot_cap, x->cfg.slot_tets);
+        failed = x->slotpatch == NULL;
+    }
+    if (failed) {
+        fprintf(stderr, "dedflow: assembly schedule %d is not available for this mesh; falling back to schedule 1 (compact colors)\n", mode);
+        x->cfg.sched_mode = 1;
+    }
+    return x->cfg.sched_mode;
+}
+
 void AssembleSystemTet(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J) {
     DflAssembleSystemTetBeta(mesh, wgalpha_dptr, dwgalpha_dptr, F, J, 1.0);
 }
@@ -105,8 +143,15 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
     if (!g_quiet) printf("Assemble: %s %s\n", F ? "F" : "", J ? "J" : "");
     value_type* val = NULL;
     const CSRAttr* spy = NULL;
+    b32 scratch = FALSE;
     if (J) {
-        spy = block_pattern(J, &val);
+        spy = block_pattern(J, &val, &scratch);
+        const int before = x->cfg.sched_mode;
+        if (ensure_lhs_schedule(mesh, spy) != before && beta_J == 0.0) {
+            /* the caller counted on an overwriting schedule; the colored scatter adds */
+            HIPGUARD(hipMemsetAsync(val, 0, (size_t)spy->nnz * 16 * sizeof(value_type), s));
+            beta_J = 1.0;
+        }
         if (x->cfg.sched_mode < 2) ensure_nzmap(mesh, spy);
     }
     /* packed gather records (one line per node) and packed residual accumulator */
@@ -133,11 +178,6 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
                                                             x->nodep, val, s));
     }
     if (patch_lhs) { /* schedule 2: one launch per PATCH color, each block RMW'd once per patch (host/patch.c) */
-        if (x->patch && x->patch->attr != spy) {
-            DflFreePatchSchedule(x->patch);
-            x->patch = NULL;
-        }
-        if (!x->patch) x->patch = DflBuildPatchSchedule(mesh, spy, x->cfg.patch_leaf, x->cfg.patch_cap);
         if (!x->patch->d_egeo) {
             x->patch->d_egeo = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
             dfl_elem_geometry(mesh->num_tet, x->patch->d_ien, dev->xg, x->patch->d_egeo, s);
@@ -151,24 +191,12 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
         }
     }
     if (rowpatch_lhs) { /* schedule 3: ONE launch, every workgroup owns the rows of its node patch (host/rowpatch.c) */
-        if (x->rowpatch && x->rowpatch->attr != spy) {
-            DflFreeRowPatchSchedule(x->rowpatch);
-            x->rowpatch = NULL;
-        }
-        if (!x->rowpatch) {
-            x->rowpatch = DflBuildRowPatchSchedule(mesh, spy, x->cfg.rowpatch_leaf, x->cfg.rowpatch_cap);
-        }
         const RowPatchSched* rs = x->rowpatch;
         DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_rowpatch(rs->num_patch, rs->d_ioff, rs->d_soff, rs->d_item_ea, rs->d_item_slot,
                                                                  rs->d_slot_nz, x->ien_b, x->egeo_b, x->nodep, val, beta_J,
                                                                  rs->max_slots, s));
     }
     if (slot_lhs) { /* schedule 4: ONE launch, every nodal nonzero is summed in registers by its owner lanes (host/slotpatch.c) */
-        if (x->slotpatch && x->slotpatch->attr != spy) {
-            DflFreeSlotPatchSchedule(x->slotpatch);
-            x->slotpatch = NULL;
-        }
-        if (!x->slotpatch) x->slotpatch = DflBuildSlotPatchSchedule(mesh, spy, x->cfg.slot_leaf, x->cfg.slot_cap, x->cfg.slot_tets);
         const SlotPatchSched* ss = x->slotpatch;
         DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_slot(ss->num_patch, ss->d_hdr, ss->d_ptet_ien, ss->d_slot_nz, ss->d_ldesc,
                                                              x->nodep, val, beta_J, ss->max_tets, s));
@@ -198,6 +226,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
     } else if (F) {
         dfl_unpack_rhs(N, x->Fp, F, s);
     }
+    if (J) block_done(J, scratch);
 }
 
 void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, f64* F, Matrix* J) {
@@ -210,7 +239,8 @@ void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, 
     MeshExt* x = (MeshExt*)mesh->ext;
     value_type* val = NULL;
     const CSRAttr* spy = NULL;
-    if (J) spy = block_pattern(J, &val);
+    b32 scratch = FALSE;
+    if (J) spy = block_pattern(J, &val, &scratch);
     const index_type* f2e = Mesh3DBoundF2E(mesh, group);
     const index_type* forn = Mesh3DBoundFORN(mesh, group);
     int slot = DflProfileBegin(DFL_TAG_FACE);
@@ -221,6 +251,7 @@ void AssembleSystemTetFace(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dptr, 
     if (F) dfl_face_sum_F(x->face_nn, x->face_node, x->face_node_off, x->face_node_ent, x->face_pF, N, F, s);
     if (spy) dfl_face_sum_J(x->face_nnz, x->face_nz, x->face_nz_off, x->face_nz_ent, x->face_pJ, val, s);
     DflProfileEnd(slot);
+    if (J) block_done(J, scratch);
 }
 
 void AssembleSystem(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* F, Matrix* J, Dirichlet** bcs, index_type nbc) {
@@ -236,6 +267,8 @@ void DflAssembleSystemPrepacked(Mesh3D* mesh, f64* wgalpha, f64* dwgalpha, f64* 
     DflRangePush(F && J ? "AssembleSystem(F,J)" : F ? "AssembleSystem(F)" : "AssembleSystem(J)");
     if (F) HIPGUARD(hipMemsetAsync(F, 0, (size_t)num_node * sizeof(f64) * BS, s));
     /* schedule 3 writes every row of J exactly once: the zero pass folds into that write */
+    if (J && Mesh3DNumTet(mesh) && MatrixFSBlockValues(J) && x->cfg.sched_mode >= 2)
+        (void)ensure_lhs_schedule(mesh, ((MatrixFS*)J->data)->spy1x1); /* may fall back to schedule 1: decides `overwrite` */
     const b32 overwrite = J && x->cfg.sched_mode >= 3 && Mesh3DNumTet(mesh) && MatrixFSBlockValues(J);
     if (J && !overwrite) MatrixZero(J);
     if (Mesh3DNumTet(mesh)) {

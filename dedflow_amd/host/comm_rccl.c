@@ -124,20 +124,24 @@ static void rccl_halo(void* ctx, f64* d_x) {
 }
 
 /* split form: the exchange runs on a side stream behind an event recorded on the library stream (d_x is complete),
- * the library stream goes on with the interior rows and waits for the side stream in halo_end */
+ * the library stream goes on with the interior rows and waits for the side stream in halo_end.  Between the two calls the
+ * caller may enqueue work of its own on the side stream (halo_stream): it runs behind the unpack, and halo_end makes the
+ * library stream wait for it as well -- the Krylov matvec puts the boundary rows there, so they overlap the interior rows
+ * and the library stream pays ONE wait per matvec and no launch of its own for them. */
 static void rccl_halo_begin(void* ctx, f64* d_x) {
     DflRcclComm* c = (DflRcclComm*)ctx;
     c->n_halo++;
     HIPGUARD(hipEventRecord(c->ev_ready, DflStream()));
     HIPGUARD(hipStreamWaitEvent(c->side, c->ev_ready, 0));
     rccl_halo_on(c, d_x, c->side);
-    HIPGUARD(hipEventRecord(c->ev_done, c->side));
 }
 static void rccl_halo_end(void* ctx, f64* d_x) {
     DflRcclComm* c = (DflRcclComm*)ctx;
     UNUSED(d_x);
+    HIPGUARD(hipEventRecord(c->ev_done, c->side));
     HIPGUARD(hipStreamWaitEvent(DflStream(), c->ev_done, 0));
 }
+static hipStream_t rccl_halo_stream(void* ctx) { return ((DflRcclComm*)ctx)->side; }
 
 /* collective over all ranks: every rank passes the same 128-byte id */
 DflRcclComm* DflRcclCommCreate(const char* id128, int rank, int world) {
@@ -175,19 +179,31 @@ DflRcclComm* DflRcclCommCreate(const char* id128, int rank, int world) {
     c->vt.halo_exchange = rccl_halo;
     c->vt.halo_begin = rccl_halo_begin;
     c->vt.halo_end = rccl_halo_end;
+    c->vt.halo_stream = rccl_halo_stream;
+    c->vt.rank = rank;
+    c->vt.world = world;
     c->vt.ctx = c;
     return c;
 }
 
-/* optional second communicator for the halo traffic (collective; every rank passes the same second id) */
-void DflRcclCommCreateHaloComm(DflRcclComm* c, const char* id128) {
+/* optional second communicator for the halo traffic (collective; every rank passes the same second id).  Returns 0 on
+ * success.  On failure this rank's halo traffic would share the main communicator -- which only works if EVERY rank does
+ * the same, so the caller must agree on the outcome across ranks and call DflRcclCommDropHaloComm on all of them if any
+ * failed (dedflow_amd/dist.py does). */
+int DflRcclCommCreateHaloComm(DflRcclComm* c, const char* id128) {
     rccl_unique_id id;
     memcpy(&id, id128, sizeof id);
     const int rc = R.CommInitRank(&c->halo_comm, c->world, id, c->rank);
-    if (rc != RCCL_SUCCESS) { /* not fatal: the halo traffic then shares the all-reduce communicator (never concurrent with it) */
-        fprintf(stderr, "DflRcclCommCreateHaloComm: ncclCommInitRank failed (%d), sharing the main communicator\n", rc);
+    if (rc != RCCL_SUCCESS) {
+        fprintf(stderr, "DflRcclCommCreateHaloComm: ncclCommInitRank failed (%d)\n", rc);
         c->halo_comm = NULL;
+        return 1;
     }
+    return 0;
+}
+void DflRcclCommDropHaloComm(DflRcclComm* c) {
+    if (c->halo_comm) R.CommDestroy(c->halo_comm);
+    c->halo_comm = NULL; /* halo traffic shares the all-reduce communicator (never concurrent with it on one stream) */
 }
 
 /* halo plan: send_idx / recv_idx are HOST arrays of flat dof indices into the local [u|p|..] vector,

@@ -146,7 +146,13 @@ void DflRangePush(const char* name);
 void DflRangePop(void);
 
 int DflDevicePoolEnabled(void); /* the default DEVICE allocator carves large requests out of its pool */
+void* DflDevicePoolAllocNoGrow(size_t bytes); /* from the chunks already reserved, or NULL */
 
 void DflMatrixFSRelocateBlockValues(Matrix* m, value_type* new_val); /* host/matrix.c */
+value_type* DflMatrixFSScratchBlockBegin(Matrix* m); /* reference-layout (u,p) FS matrix -> scratch block array (host/matrix.c) */
+void DflMatrixFSScratchBlockEnd(Matrix* m);
+/* host/slotpatch.c */
+int DflSlotPatchLimitCheck(int64_t num_positions, int64_t num_tets, int64_t max_contributions_of_a_position, char* why, size_t why_len);
+void DflSlotPatchSetTestLimits(int positions, int tets);
 
 #endif

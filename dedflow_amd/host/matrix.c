@@ -449,6 +449,31 @@ void MatrixFSExportSubmatrices(Matrix* m) {
                         csr_alloc_values(csr_of(fs->mat[n + 1])), DflStream());
 }
 
+/* A (u,p) MatrixFS kept in the reference's layout (MatrixFSUseReferenceLayout) handed to the library's own assembly: the
+ * kernels work on a scratch 4x4-block array -- Begin fills it from the four sub-matrix arrays, End writes it back.  Two
+ * conversion passes per assembly call: the price of Level-B compatibility, not the hot path.  NULL when the
+ * matrix does not hold the (u,p) 2x2 layout of main.c:374-391. */
+value_type* DflMatrixFSScratchBlockBegin(Matrix* m) {
+    if (!m || m->type != MAT_TYPE_FS) return NULL;
+    MatrixFS* fs = fs_of(m);
+    if (fs->block_mode) return fs->block_val;
+    if (!fs->spy1x1 || !fs_is_up_layout(fs)) return NULL;
+    const index_type n = fs->n_offset;
+    if (!fs->block_val) fs->block_val = (value_type*)CdamMallocDevice((ptrdiff_t)fs->spy1x1->nnz * 16 * SIZE_OF(value_type));
+    dfl_block_import_fs(fs->spy1x1->num_row, fs->spy1x1->row_ptr, fs->block_val, csr_alloc_values(csr_of(fs->mat[0])),
+                        csr_alloc_values(csr_of(fs->mat[1])), csr_alloc_values(csr_of(fs->mat[n])),
+                        csr_alloc_values(csr_of(fs->mat[n + 1])), DflStream());
+    return fs->block_val;
+}
+void DflMatrixFSScratchBlockEnd(Matrix* m) {
+    MatrixFS* fs = fs_of(m);
+    if (fs->block_mode || !fs->block_val) return;
+    const index_type n = fs->n_offset;
+    dfl_block_export_fs(fs->spy1x1->num_row, fs->spy1x1->row_ptr, fs->block_val, csr_alloc_values(csr_of(fs->mat[0])),
+                        csr_alloc_values(csr_of(fs->mat[1])), csr_alloc_values(csr_of(fs->mat[n])),
+                        csr_alloc_values(csr_of(fs->mat[n + 1])), DflStream());
+}
+
 void MatrixFSImportSubmatrices(Matrix* m) {
     MatrixFS* fs = fs_of(m);
     if (!fs->block_mode) return;

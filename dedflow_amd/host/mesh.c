@@ -177,7 +177,10 @@ void Mesh3DColor(Mesh3D* mesh) {
  * (mesh->color / batch_offset / batch_ind are bit-identical and remain the public result);
  * what the assembly kernels EXECUTE is a second, balanced greedy coloring with ~4x fewer and
  * ~4x larger conflict-free launches.  First-fit over node bit masks, least-loaded free class. */
-static void build_compact_schedule(Mesh3D* mesh, MeshExt* x) {
+/* FALSE (nothing allocated) when the mesh needs more than 64 classes -- a vertex shared by more than 64 tets, which the
+ * reference's own limits allow (a row of <= 64 nonzeros, csr.c:10, bounds a closed fan at 2 * 63 - 4 = 122 tets): the caller
+ * then executes the reference's JPL color batches instead (they go up to 256 colors). */
+static b32 build_compact_schedule(Mesh3D* mesh, MeshExt* x) {
     const index_type T = mesh->num_tet, N = mesh->num_node;
     const index_type* ien = mesh->host->ien;
     u64* node_mask = (u64*)CdamMallocHost((ptrdiff_t)N * (ptrdiff_t)sizeof(u64));
@@ -193,7 +196,13 @@ static void build_compact_schedule(Mesh3D* mesh, MeshExt* x) {
         for (int c = 0; c < nopen; ++c)
             if (!((used >> c) & 1ULL) && (best < 0 || count[c] < count[best])) best = c;
         if (best < 0) {
-            ASSERT(nopen < 64 && "compact schedule needs more than 64 classes");
+            if (nopen == 64) {
+                fprintf(stderr, "dedflow: the compact assembly schedule needs more than 64 conflict-free classes (a vertex of tet %d "
+                                "is shared by more than 64 tets); executing the reference's color batches instead\n", e);
+                CdamFreeHost(cls, 0);
+                CdamFreeHost(node_mask, 0);
+                return FALSE;
+            }
             best = nopen++;
         }
         cls[e] = (u8)best;
@@ -217,6 +226,7 @@ static void build_compact_schedule(Mesh3D* mesh, MeshExt* x) {
     x->h_sched_elem = ind; /* schedule position -> element id, kept for the row-owner schedule builder */
     CdamFreeHost(cls, 0);
     CdamFreeHost(node_mask, 0);
+    return TRUE;
 }
 
 /* Mesh3DGenerateColorBatch, src/Mesh.c:165-206.  The per-color count + copy_if passes
@@ -236,16 +246,15 @@ void Mesh3DGenerateColorBatch(Mesh3D* mesh) {
     if (x->sched_offset) CdamFreeHost(x->sched_offset, 0);
     if (x->h_sched_elem) CdamFreeHost(x->h_sched_elem, 0);
     x->h_sched_elem = NULL;
-    if (x->cfg.sched_mode == 0) {
-        /* execution schedule == the reference's JPL color batches */
+    if (x->cfg.sched_mode == 0 || !build_compact_schedule(mesh, x)) {
+        /* execution schedule == the reference's JPL color batches (asked for, or the compact schedule refused the mesh: the
+           colored kernels of schedule 1 then run one launch per reference color; schedules 2-4 are unaffected) */
         x->sched_num = nc;
         x->sched_offset = (index_type*)CdamMallocHost(SIZE_OF(index_type) * (nc + 1));
         memcpy(x->sched_offset, mesh->batch_offset, sizeof(index_type) * (size_t)(nc + 1));
         dfl_gather_ien(T, mesh->device->ien, mesh->batch_ind, x->ien_b, DflStream());
         x->h_sched_elem = (index_type*)CdamMallocHost((ptrdiff_t)T * SIZE_OF(index_type));
         HIPGUARD(hipMemcpy(x->h_sched_elem, mesh->batch_ind, sizeof(index_type) * (size_t)T, D2H));
-    } else {
-        build_compact_schedule(mesh, x);
     }
     HIPGUARD(hipStreamSynchronize(DflStream()));
 }

@@ -214,7 +214,14 @@ PatchSched* DflBuildPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type l
         for (int k = 0; k < nopen; ++k)
             if (!((used >> k) & 1ULL) && (best < 0 || load[k] < load[best])) best = k;
         if (best < 0) {
-            ASSERT(nopen < 64 && "patch schedule needs more than 64 colors");
+            if (nopen == 64) { /* patches around a vertex shared by very many tets: more conflict classes than a 64-bit mask */
+                fprintf(stderr, "tet-patch schedule (assembly schedule 2) cannot hold this mesh: more than 64 patch colors (patch %d)\n", p);
+                for (index_type q = 0; q < P; ++q) free(keys_of[q]);
+                free(pcolor); free(node_mask); free(lslot_rcb); free(keys_of); free(nblk); free(x.out); free(idx); free(c);
+                free(ci); free(rp);
+                CdamFreeHost(ps, SIZE_OF(PatchSched));
+                return NULL;
+            }
             best = nopen++;
         }
         pcolor[p] = (u8)best;

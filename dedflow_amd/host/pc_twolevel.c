@@ -23,13 +23,23 @@
  * DILU alone: 120 at M = 119, ~600 at M = 203), independent of the aggregate size (8 or 64), of the inner tolerance and of a
  * damping factor on the smoother step (0.5 - 1.3).  With the time step fixed the CFL number grows with the mesh (10 at M = 203
  * for |u| = 1): the momentum block becomes advection-dominated, which a piecewise-constant coarse space does not follow.
- * Single GPU only for now.
+ *
+ * Element-partitioned matrices (PCCreateTwoLevelDist; one process per GPU, owned rows first): every rank cuts aggregates out
+ * of the nodes it OWNS and numbers them globally (rank order); ghost nodes learn their aggregate through one halo exchange.
+ * A rank's owned rows give complete rows of Ac = P^T A P for its own aggregates; pattern (once) and values (every PCSetup)
+ * are then REPLICATED -- every rank fills its rows of a zero buffer and the buffers are summed by DflComm.allreduce_sum,
+ * which is an exact all-gather (x + 0 = x) -- so the coarse problem (<= 130k nodes at 50M tets) is solved redundantly and
+ * identically on every rank with no collective inside the inner iteration.  Per application the partitioned form adds one
+ * halo exchange (ghost entries of z for t = r - A z) and one all-reduce of the restricted residual (4 Nc doubles); the
+ * smoother is the rank-local DILU (block-diagonal across ranks, host/pc_dilu.c).  The K-cycle levels below work on the
+ * replicated matrices and need no communication at all.
  */
 #include <string.h>
 #include <omp.h>
 #include "dedflow.h"
 #include "dedflow_kernels.h"
 #include "host_private.h"
+#include "solver_private.h"
 #include "rcb.h"
 
 typedef struct PCTwoLevel {
@@ -50,6 +60,11 @@ typedef struct PCTwoLevel {
     const f64* xyz;              /* [N][3] host coordinates the aggregates are cut from */
     f64* xyz_owned;              /* coarse levels own theirs (aggregate centroids) */
     int level;
+    /* element-partitioned fine level */
+    b32 dist;                    /* comm below is valid and world > 1 */
+    DflComm comm;
+    index_type n_owned;          /* rows this rank aggregates (== N on one GPU) */
+    index_type agg_base, Nc_local; /* this rank's aggregates are [agg_base, agg_base + Nc_local) of the Nc global ones */
 } PCTwoLevel;
 static PC* tl_create(Matrix* mat, const f64* xyz, f64* xyz_owned, index_type agg_size, int level);
 
@@ -118,10 +133,30 @@ static void tl_release(PCTwoLevel* d) {
     d->c3x3 = d->c3x1 = d->c1x3 = d->c1x1b = d->c1x1 = NULL;
 }
 
+/* ---- replication helpers (partitioned fine level) -------------------------------------------------------------
+ * Small integer tables travel as f64 (exact below 2^53) through the one reduction DflComm offers: every rank writes its
+ * own entries into a zero buffer, the sum over ranks is the concatenation. */
+static void dist_sum_f64(const DflComm* c, f64* d_buf, int64_t n) {
+    const int64_t chunk = (int64_t)1 << 30;
+    for (int64_t o = 0; o < n; o += chunk) c->allreduce_sum(c->ctx, d_buf + o, (index_type)(n - o < chunk ? n - o : chunk));
+}
+/* host array of `total` doubles, this rank's `count` entries at `at`, zero elsewhere -> the sum over all ranks */
+static void dist_replicate(const DflComm* c, f64* host, int64_t total) {
+    if (total <= 0) return;
+    hipStream_t s = DflStream();
+    f64* d = (f64*)CdamMallocDevice((ptrdiff_t)total * SIZE_OF(f64));
+    HIPGUARD(hipMemcpyAsync(d, host, sizeof(f64) * (size_t)total, H2D, s));
+    dist_sum_f64(c, d, total);
+    HIPGUARD(hipMemcpyAsync(host, d, sizeof(f64) * (size_t)total, D2H, s));
+    HIPGUARD(hipStreamSynchronize(s));
+    CdamFreeDevice(d, 0);
+}
+
 /* aggregates, coarse pattern, Galerkin lists, coarse matrix + solver: once per (mesh, fine pattern) */
 static void tl_build(PCTwoLevel* d) {
     const CSRAttr* spy = d->spy;
     const index_type N = d->N;
+    const index_type no = d->dist ? d->n_owned : N; /* rows aggregated here */
     const f64* xg = d->xyz;
     int nt = omp_get_max_threads();
     if (getenv("DFL_HOST_THREADS")) nt = atoi(getenv("DFL_HOST_THREADS"));
@@ -133,35 +168,75 @@ static void tl_build(PCTwoLevel* d) {
     index_type* ci = (index_type*)malloc(sizeof(index_type) * (size_t)spy->nnz);
     HIPGUARD(hipMemcpy(rp, spy->row_ptr, sizeof(index_type) * ((size_t)N + 1), D2H));
     HIPGUARD(hipMemcpy(ci, spy->col_ind, sizeof(index_type) * (size_t)spy->nnz, D2H));
-    /* 1. aggregates */
-    index_type* idx = (index_type*)malloc(sizeof(index_type) * (size_t)N);
-    for (index_type i = 0; i < N; ++i) idx[i] = i;
+    d->d_t = (f64*)CdamMallocDevice((ptrdiff_t)d->n * SIZE_OF(f64));
+    /* 1. aggregates of the nodes this rank owns */
+    index_type* idx = (index_type*)malloc(sizeof(index_type) * (size_t)(no > 0 ? no : 1));
+    for (index_type i = 0; i < no; ++i) idx[i] = i;
     Rcb x = {xg, idx, d->agg_size, NULL, 0, 1024};
     x.out = (Range*)malloc(sizeof(Range) * (size_t)x.capout);
+    if (no > 0) {
 #pragma omp parallel num_threads(nt)
 #pragma omp single
-    rcb_split(&x, 0, N);
-    qsort(x.out, (size_t)x.nout, sizeof(Range), cmp_range);
-    const index_type Nc = x.nout;
-    index_type* agg = (index_type*)malloc(sizeof(index_type) * (size_t)N);
-    index_type* aoff = (index_type*)malloc(sizeof(index_type) * ((size_t)Nc + 1));
-    for (index_type I = 0; I < Nc; ++I) {
-        aoff[I] = x.out[I].lo;
-        qsort(idx + x.out[I].lo, (size_t)(x.out[I].hi - x.out[I].lo), sizeof(index_type), cmp_i32); /* ascending node id */
-        for (index_type k = x.out[I].lo; k < x.out[I].hi; ++k) agg[idx[k]] = I;
+        rcb_split(&x, 0, no);
     }
-    aoff[Nc] = N;
-    /* 2. coarse pattern: row I = sorted unique aggregates of the neighbours of its nodes */
-    index_type* crp = (index_type*)malloc(sizeof(index_type) * ((size_t)Nc + 1));
-    index_type** rows = (index_type**)malloc(sizeof(index_type*) * (size_t)Nc);
-    index_type* rlen = (index_type*)malloc(sizeof(index_type) * (size_t)Nc);
+    qsort(x.out, (size_t)x.nout, sizeof(Range), cmp_range);
+    const index_type Ncl = x.nout;
+    /* global numbering of the aggregates: rank order */
+    index_type base = 0, Nc = Ncl;
+    int64_t N_global = N;
+    if (d->dist) {
+        const int W = d->comm.world;
+        f64* cnt = (f64*)calloc((size_t)2 * W, sizeof(f64));
+        cnt[d->comm.rank] = (f64)Ncl;
+        cnt[W + d->comm.rank] = (f64)no;
+        dist_replicate(&d->comm, cnt, 2 * (int64_t)W);
+        int64_t tot = 0;
+        N_global = 0;
+        for (int q = 0; q < W; ++q) {
+            if (q == d->comm.rank) base = (index_type)tot;
+            tot += (int64_t)cnt[q];
+            N_global += (int64_t)cnt[W + q];
+        }
+        ASSERT(tot < 2147483647LL / 8);
+        Nc = (index_type)tot;
+        free(cnt);
+    }
+    index_type* agg = (index_type*)malloc(sizeof(index_type) * (size_t)N); /* GLOBAL aggregate of every local node */
+    index_type* aoff = (index_type*)malloc(sizeof(index_type) * ((size_t)Nc + 1));
+    for (index_type g = 0; g <= base; ++g) aoff[g] = 0;
+    for (index_type I = 0; I < Ncl; ++I) {
+        aoff[base + I] = x.out[I].lo;
+        qsort(idx + x.out[I].lo, (size_t)(x.out[I].hi - x.out[I].lo), sizeof(index_type), cmp_i32); /* ascending node id */
+        for (index_type k = x.out[I].lo; k < x.out[I].hi; ++k) agg[idx[k]] = base + I;
+    }
+    for (index_type g = base + Ncl; g <= Nc; ++g) aoff[g] = no; /* the other ranks' aggregates hold none of our nodes */
+    if (d->dist && N > no) {
+        /* ghost nodes: the aggregate their owner gave them, through the solver's own halo exchange (ids ride in the u0 slot) */
+        hipStream_t s = DflStream();
+        f64* h = (f64*)calloc((size_t)d->n, sizeof(f64));
+        for (index_type i = 0; i < no; ++i) h[(size_t)3 * i] = (f64)agg[i];
+        HIPGUARD(hipMemcpyAsync(d->d_t, h, sizeof(f64) * (size_t)d->n, H2D, s));
+        d->comm.halo_exchange(d->comm.ctx, d->d_t);
+        HIPGUARD(hipMemcpyAsync(h, d->d_t, sizeof(f64) * (size_t)d->n, D2H, s));
+        HIPGUARD(hipStreamSynchronize(s));
+        for (index_type i = no; i < N; ++i) {
+            agg[i] = (index_type)h[(size_t)3 * i];
+            ASSERT(agg[i] >= 0 && agg[i] < Nc && (agg[i] < base || agg[i] >= base + Ncl));
+        }
+        free(h);
+    } else if (d->dist) {
+        d->comm.halo_exchange(d->comm.ctx, d->d_t); /* a rank without ghosts still takes part in the exchange */
+    }
+    /* 2. coarse pattern: row I = sorted unique aggregates of the neighbours of its nodes (own rows here, then replicated) */
+    index_type** rows = (index_type**)malloc(sizeof(index_type*) * (size_t)(Ncl > 0 ? Ncl : 1));
+    index_type* rlen = (index_type*)malloc(sizeof(index_type) * (size_t)(Ncl > 0 ? Ncl : 1));
 #pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
-    for (index_type I = 0; I < Nc; ++I) {
+    for (index_type I = 0; I < Ncl; ++I) {
         size_t cap = 0;
-        for (index_type k = aoff[I]; k < aoff[I + 1]; ++k) cap += (size_t)(rp[idx[k] + 1] - rp[idx[k]]);
+        for (index_type k = aoff[base + I]; k < aoff[base + I + 1]; ++k) cap += (size_t)(rp[idx[k] + 1] - rp[idx[k]]);
         index_type* tmp = (index_type*)malloc(sizeof(index_type) * (cap > 0 ? cap : 1));
         size_t m = 0;
-        for (index_type k = aoff[I]; k < aoff[I + 1]; ++k)
+        for (index_type k = aoff[base + I]; k < aoff[base + I + 1]; ++k)
             for (index_type z = rp[idx[k]]; z < rp[idx[k] + 1]; ++z) tmp[m++] = agg[ci[z]];
         qsort(tmp, m, sizeof(index_type), cmp_i32);
         index_type u = 0;
@@ -170,22 +245,43 @@ static void tl_build(PCTwoLevel* d) {
         rows[I] = tmp;
         rlen[I] = u;
     }
-    crp[0] = 0;
-    for (index_type I = 0; I < Nc; ++I) {
-        ASSERT((int64_t)crp[I] + rlen[I] < 2147483647LL);
-        crp[I + 1] = crp[I] + rlen[I];
+    index_type* crp = (index_type*)malloc(sizeof(index_type) * ((size_t)Nc + 1));
+    if (d->dist) {
+        f64* len = (f64*)calloc((size_t)(Nc > 0 ? Nc : 1), sizeof(f64));
+        for (index_type I = 0; I < Ncl; ++I) len[base + I] = (f64)rlen[I];
+        dist_replicate(&d->comm, len, Nc);
+        crp[0] = 0;
+        for (index_type g = 0; g < Nc; ++g) {
+            ASSERT((int64_t)crp[g] + (int64_t)len[g] < 2147483647LL / 16);
+            crp[g + 1] = crp[g] + (index_type)len[g];
+        }
+        free(len);
+    } else {
+        crp[0] = 0;
+        for (index_type I = 0; I < Nc; ++I) {
+            ASSERT((int64_t)crp[I] + rlen[I] < 2147483647LL);
+            crp[I + 1] = crp[I] + rlen[I];
+        }
     }
     const index_type nnzc = crp[Nc];
     index_type* cci = (index_type*)malloc(sizeof(index_type) * (size_t)(nnzc > 0 ? nnzc : 1));
-    for (index_type I = 0; I < Nc; ++I) {
-        memcpy(cci + crp[I], rows[I], sizeof(index_type) * (size_t)rlen[I]);
+    for (index_type I = 0; I < Ncl; ++I) {
+        memcpy(cci + crp[base + I], rows[I], sizeof(index_type) * (size_t)rlen[I]);
         free(rows[I]);
     }
-    /* 3. Galerkin lists: coarse nonzero -> fine nonzeros, ascending fine index */
+    if (d->dist) {
+        f64* col = (f64*)calloc((size_t)(nnzc > 0 ? nnzc : 1), sizeof(f64));
+        for (index_type z = crp[base]; z < crp[base + Ncl]; ++z) col[z] = (f64)cci[z];
+        dist_replicate(&d->comm, col, nnzc);
+        for (index_type z = 0; z < nnzc; ++z) cci[z] = (index_type)col[z];
+        free(col);
+    }
+    /* 3. Galerkin lists: coarse nonzero -> fine nonzeros of the OWNED fine rows (they come first), ascending fine index */
+    const index_type fnz = rp[no];
     index_type* goff = (index_type*)calloc((size_t)nnzc + 1, sizeof(index_type));
-    index_type* fz2cz = (index_type*)malloc(sizeof(index_type) * (size_t)spy->nnz);
+    index_type* fz2cz = (index_type*)malloc(sizeof(index_type) * (size_t)(fnz > 0 ? fnz : 1));
 #pragma omp parallel for schedule(static) num_threads(nt)
-    for (index_type i = 0; i < N; ++i) {
+    for (index_type i = 0; i < no; ++i) {
         const index_type I = agg[i];
         for (index_type z = rp[i]; z < rp[i + 1]; ++z) {
             const index_type J = agg[ci[z]];
@@ -197,21 +293,21 @@ static void tl_build(PCTwoLevel* d) {
             fz2cz[z] = lo;
         }
     }
-    for (index_type z = 0; z < spy->nnz; ++z) goff[fz2cz[z] + 1]++;
+    for (index_type z = 0; z < fnz; ++z) goff[fz2cz[z] + 1]++;
     for (index_type c = 0; c < nnzc; ++c) goff[c + 1] += goff[c];
-    index_type* gidx = (index_type*)malloc(sizeof(index_type) * (size_t)spy->nnz);
+    index_type* gidx = (index_type*)malloc(sizeof(index_type) * (size_t)(fnz > 0 ? fnz : 1));
     {
         index_type* cur = (index_type*)malloc(sizeof(index_type) * (size_t)(nnzc > 0 ? nnzc : 1));
         memcpy(cur, goff, sizeof(index_type) * (size_t)nnzc);
-        for (index_type z = 0; z < spy->nnz; ++z) gidx[cur[fz2cz[z]]++] = z;
+        for (index_type z = 0; z < fnz; ++z) gidx[cur[fz2cz[z]]++] = z;
         free(cur);
     }
     /* 4. upload; coarse matrix objects in the reference's own shapes */
 #define UP(dst, src, cnt)                                                                             \
     dst = (index_type*)CdamMallocDevice((ptrdiff_t)((cnt) > 0 ? (cnt) : 1) * SIZE_OF(index_type));    \
     HIPGUARD(hipMemcpy(dst, src, sizeof(index_type) * (size_t)(cnt), H2D));
-    UP(d->d_agg, agg, N) UP(d->d_aoff, aoff, Nc + 1) UP(d->d_anode, idx, N)
-    UP(d->d_goff, goff, nnzc + 1) UP(d->d_gidx, gidx, spy->nnz)
+    UP(d->d_agg, agg, N) UP(d->d_aoff, aoff, Nc + 1) UP(d->d_anode, idx, no)
+    UP(d->d_goff, goff, nnzc + 1) UP(d->d_gidx, gidx, fnz)
     CSRAttr* c = (CSRAttr*)CdamMallocHost(SIZE_OF(CSRAttr));
     memset(c, 0, sizeof *c);
     c->num_row = c->num_col = Nc;
@@ -235,15 +331,17 @@ static void tl_build(PCTwoLevel* d) {
     ASSERT(MatrixFSBlockValues(d->Ac));
     index_type coarsest = 262144;
     if (getenv("DFL_TL_COARSEST")) coarsest = atoi(getenv("DFL_TL_COARSEST"));
-    const int recurse = Nc > coarsest && Nc * 2 < N;
+    const int recurse = Nc > coarsest && (int64_t)Nc * 2 < N_global;
     index_type kcycle = 8;
     if (getenv("DFL_TL_KCYCLE")) kcycle = atoi(getenv("DFL_TL_KCYCLE"));
     if (getenv("DFL_TL_INNER_RTOL")) d->inner_rtol = atof(getenv("DFL_TL_INNER_RTOL"));
     d->cksp = KrylovCreateGMRES(recurse ? kcycle : d->inner_maxit, 0.0, d->inner_rtol, NULL);
     KrylovSetVerbose(d->cksp, FALSE);
+    DflKrylovMarkInner(d->cksp); /* a coarse solver never times basis placements in the middle of an outer solve */
     if (recurse) {
-        f64* cx = (f64*)malloc(sizeof(f64) * 3 * (size_t)Nc);
-        for (index_type I = 0; I < Nc; ++I) {
+        /* centroids of ALL aggregates (the level below works on the replicated coarse matrix) */
+        f64* cx = (f64*)calloc(3 * (size_t)Nc, sizeof(f64));
+        for (index_type I = base; I < base + Ncl; ++I) {
             f64 sx = 0, sy = 0, sz = 0;
             for (index_type k = aoff[I]; k < aoff[I + 1]; ++k) {
                 sx += xg[(size_t)idx[k] * 3];
@@ -255,6 +353,7 @@ static void tl_build(PCTwoLevel* d) {
             cx[(size_t)I * 3 + 1] = sy * w;
             cx[(size_t)I * 3 + 2] = sz * w;
         }
+        if (d->dist) dist_replicate(&d->comm, cx, 3 * (int64_t)Nc);
         d->cksp->pc = tl_create(d->Ac, cx, cx, d->agg_size, d->level + 1); /* destroyed with the inner solver */
         KrylovSetFlexible(d->cksp, TRUE);
         KrylovSetCheckInterval(d->cksp, 2);
@@ -263,13 +362,14 @@ static void tl_build(PCTwoLevel* d) {
         KrylovSetCheckInterval(d->cksp, 4);
     }
     d->Nc = Nc;
-    d->d_t = (f64*)CdamMallocDevice((ptrdiff_t)d->n * SIZE_OF(f64));
+    d->Nc_local = Ncl;
+    d->agg_base = base;
     d->d_rc = (f64*)CdamMallocDevice((ptrdiff_t)Nc * 6 * SIZE_OF(f64));
     d->d_xc = (f64*)CdamMallocDevice((ptrdiff_t)Nc * 6 * SIZE_OF(f64));
     if (verbose)
-        fprintf(stderr, "[twolevel] level %d: %d nodes -> %d aggregates (<= %d nodes), coarse nnz %d (%.1f per row), %s below, %.2f s\n",
-                d->level, N, Nc, d->agg_size, nnzc, (double)nnzc / (double)(Nc > 0 ? Nc : 1), recurse ? "another level" : "DILU-GMRES",
-                omp_get_wtime() - t0);
+        fprintf(stderr, "[twolevel] level %d%s: %d nodes -> %d aggregates (<= %d nodes)%s, coarse nnz %d (%.1f per row), %s below, %.2f s\n",
+                d->level, d->dist ? " (partitioned)" : "", no, Ncl, d->agg_size, d->dist ? " of this rank" : "", nnzc,
+                (double)nnzc / (double)(Nc > 0 ? Nc : 1), recurse ? "another level" : "DILU-GMRES", omp_get_wtime() - t0);
     free(gidx); free(fz2cz); free(goff); free(cci); free(rlen); free(rows); free(crp); free(aoff); free(agg); free(x.out); free(idx);
     free(ci); free(rp);
 }
@@ -278,14 +378,17 @@ static void tl_setup(PC* pc) {
     PCTwoLevel* d = (PCTwoLevel*)pc->data;
     Matrix* A = (Matrix*)pc->mat;
     MatrixFS* fs = (MatrixFS*)A->data;
-    if (d->spy != fs->spy1x1) {
+    if (d->spy != fs->spy1x1 || (d->dist && d->n_owned != MatrixFSOwnedRows(A))) {
         tl_release(d);
         d->spy = fs->spy1x1;
         d->N = fs->spy1x1->num_row;
+        d->n_owned = MatrixFSOwnedRows(A);
         tl_build(d);
     }
     PCSetup(d->smoother);
     dfl_amg_galerkin(d->c1x1->nnz, d->d_goff, d->d_gidx, MatrixFSBlockValues(A), MatrixFSBlockValues(d->Ac), DflStream());
+    /* partitioned: every rank summed the coarse rows of its own aggregates (the lists of the others are empty: zeros) */
+    if (d->dist) dist_sum_f64(&d->comm, MatrixFSBlockValues(d->Ac), (int64_t)d->c1x1->nnz * 16);
     PCSetup((PC*)d->cksp->pc); /* the levels below: their coarse matrices change here, not between applications */
 }
 
@@ -297,12 +400,15 @@ static void tl_apply(PC* pc, value_type* r, value_type* z) {
     PCDILUSetActiveLength(d->smoother, n);
     PCApply(d->smoother, r, z);                 /* z = S r (copies the phi / T tail when n > 4N) */
     dfl_dcopy(4 * N, r, d->d_t, s);
-    MatrixAMVPBY(A, -1.0, z, 1.0, d->d_t);      /* t = r - A z on the (u,p) part */
+    if (d->dist) d->comm.halo_exchange(d->comm.ctx, z); /* the owned rows of A read ghost entries of z */
+    MatrixAMVPBY(A, -1.0, z, 1.0, d->d_t);      /* t = r - A z on the (u,p) part (owned rows) */
     dfl_amg_restrict(Nc, d->d_aoff, d->d_anode, N, d->d_t, d->d_rc, s);
+    /* partitioned: rc is zero outside this rank's aggregates; the sum over ranks is the whole coarse residual, on every rank */
+    if (d->dist) dist_sum_f64(&d->comm, d->d_rc, 4 * (int64_t)Nc);
     HIPGUARD(hipMemsetAsync(d->d_xc, 0, (size_t)Nc * 6 * sizeof(f64), s));
     DflKrylovSolvePrepared(d->cksp, d->Ac, d->d_xc, d->d_rc); /* the phi / T tail of rc is zero: the solve runs on 4 Nc */
     d->inner_iterations += KrylovGetStats(d->cksp)->iterations;
-    dfl_amg_prolong_add(N, d->d_agg, Nc, d->d_xc, z, s);
+    dfl_amg_prolong_add_rows(d->dist ? d->n_owned : N, N, d->d_agg, Nc, d->d_xc, z, s);
 }
 
 static void tl_destroy(PC* pc) {
@@ -313,17 +419,30 @@ static void tl_destroy(PC* pc) {
     CdamFreeHost(d, SIZE_OF(PCTwoLevel));
 }
 
-PC* PCCreateTwoLevel(Matrix* mat, const Mesh3D* mesh, index_type agg_size) {
+PC* PCCreateTwoLevelDist(Matrix* mat, const Mesh3D* mesh, index_type agg_size, const DflComm* comm) {
     if (!mat || !MatrixFSBlockValues(mat) || !mesh || !mesh->host || mesh->num_node != ((MatrixFS*)mat->data)->spy1x1->num_row) {
         fprintf(stderr, "PCCreateTwoLevel: needs the block-mode (u,p) field-split matrix and the mesh it was built on\n");
         return NULL;
     }
-    if (MatrixFSOwnedRows(mat) != mesh->num_node) {
-        fprintf(stderr, "PCCreateTwoLevel: element-partitioned matrices are not supported yet\n");
+    const b32 partitioned = comm && comm->world > 1;
+    if (!partitioned && MatrixFSOwnedRows(mat) != mesh->num_node) {
+        fprintf(stderr, "PCCreateTwoLevel: an element-partitioned matrix needs the partition's DflComm with rank / world set "
+                        "(PCCreateTwoLevelDist)\n");
         return NULL;
     }
-    return tl_create(mat, mesh->host->xg, NULL, agg_size, 0);
+    if (partitioned && (comm->rank < 0 || comm->rank >= comm->world || !comm->allreduce_sum || !comm->halo_exchange)) {
+        fprintf(stderr, "PCCreateTwoLevelDist: the communicator lacks rank / world or a callback\n");
+        return NULL;
+    }
+    PC* pc = tl_create(mat, mesh->host->xg, NULL, agg_size, 0);
+    if (partitioned) {
+        PCTwoLevel* d = (PCTwoLevel*)pc->data;
+        d->dist = TRUE;
+        d->comm = *comm;
+    }
+    return pc;
 }
+PC* PCCreateTwoLevel(Matrix* mat, const Mesh3D* mesh, index_type agg_size) { return PCCreateTwoLevelDist(mat, mesh, agg_size, NULL); }
 
 static PC* tl_create(Matrix* mat, const f64* xyz, f64* xyz_owned, index_type agg_size, int level) {
     PC* pc = (PC*)CdamMallocHost(SIZE_OF(PC));

@@ -154,7 +154,13 @@ RowPatchSched* DflBuildRowPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_
             ni += vp[n + 1] - vp[n];
             ns += rp[n + 1] - rp[n];
         }
-        ASSERT(ns <= 4095 && "row-patch LDS table holds at most 4095 block slots");
+        if (ns > 4095) { /* a single node with a row of > 4095 nonzeros: the LDS table holds 12-bit slot ids */
+            fprintf(stderr, "row-owner schedule (assembly schedule 3) cannot hold this mesh: %lld nodal nonzeros in one node patch "
+                            "(limit 4095), around node %d\n", (long long)ns, idx[x.out[p].lo]);
+            free(soff); free(ioff); free(x.out); free(idx); free(ve); free(vp); free(ci); free(rp);
+            CdamFreeHost(ps, SIZE_OF(RowPatchSched));
+            return NULL;
+        }
         ioff[p + 1] = (index_type)(ioff[p] + ni);
         soff[p + 1] = (index_type)(soff[p] + ns);
         if (ns > maxs) maxs = (index_type)ns;

@@ -38,12 +38,16 @@ void DflGuardPrivate(hipError_t code, const char* file, int line) {
  * driver's own "VRAM used" figure does, and rocm_smi reads it (read-only, no privileges).  rocm_smi is bound at run time
  * like RCCL and ROCTx; when it is missing every function below reports "unknown" and nobody waits. */
 static struct {
-    int state; /* 0 = not tried, 1 = usable, -1 = unavailable */
-    uint32_t dv;
+    int state; /* 0 = not tried, 1 = library bound, -1 = unavailable */
     int (*mem_usage)(uint32_t, int, uint64_t*);
     int (*clk_freq)(uint32_t, int, void*);
+    int (*num)(uint32_t*);
+    int (*pci)(uint32_t, uint64_t*);
+    int dv_of[16]; /* rocm_smi index of HIP device d: 0 = not looked up yet, -1 = no match, i + 1 = index i */
 } g_smi;
-typedef struct { uint8_t has_deep_sleep; uint32_t num_supported, current; uint64_t frequency[33]; } SmiFrequencies; /* rsmi_frequencies_t */
+/* rsmi_frequencies_t of rocm_smi.h (ROCm 6-7: bool has_deep_sleep; uint32_t num_supported, current; uint64_t frequency[33]),
+ * mirrored by hand because the header is not a build dependency; rocm_smi writes at most this many bytes into it */
+typedef struct { uint8_t has_deep_sleep; uint32_t num_supported, current; uint64_t frequency[33]; } SmiFrequencies;
 
 static void smi_bind(void) {
     if (g_smi.state) return;
@@ -54,36 +58,47 @@ static void smi_bind(void) {
     if (!h) h = dlopen("/opt/rocm/lib/librocm_smi64.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) return;
     int (*init)(uint64_t) = (int (*)(uint64_t))dlsym(h, "rsmi_init");
-    int (*num)(uint32_t*) = (int (*)(uint32_t*))dlsym(h, "rsmi_num_monitor_devices");
-    int (*pci)(uint32_t, uint64_t*) = (int (*)(uint32_t, uint64_t*))dlsym(h, "rsmi_dev_pci_id_get");
+    *(void**)(&g_smi.num) = dlsym(h, "rsmi_num_monitor_devices");
+    *(void**)(&g_smi.pci) = dlsym(h, "rsmi_dev_pci_id_get");
     *(void**)(&g_smi.mem_usage) = dlsym(h, "rsmi_dev_memory_usage_get");
     *(void**)(&g_smi.clk_freq) = dlsym(h, "rsmi_dev_gpu_clk_freq_get");
-    if (!init || !num || !pci || !g_smi.mem_usage || init(0) != 0) return;
-    /* the rocm_smi index of the current HIP device: match PCI domain : bus : device . function */
+    if (!init || !g_smi.num || !g_smi.pci || !g_smi.mem_usage || init(0) != 0) return;
+    g_smi.state = 1;
+}
+
+/* rocm_smi index of the CURRENT HIP device (a rank may select its device after Init()): matched by PCI domain : bus :
+ * device . function, looked up once per HIP device; -1 when unknown */
+static int smi_device(void) {
+    smi_bind();
+    if (g_smi.state != 1) return -1;
     int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (dev < 0 || dev >= 16) return -1;
+    if (g_smi.dv_of[dev]) return g_smi.dv_of[dev] - 1 >= 0 ? g_smi.dv_of[dev] - 1 : -1;
+    g_smi.dv_of[dev] = -1;
     char bus[64] = {0};
     unsigned dom = 0, b = 0, d = 0, f = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) { (void)hipGetLastError(); return; }
-    if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) return;
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) return -1;
     uint32_t n = 0;
-    if (num(&n) != 0) return;
+    if (g_smi.num(&n) != 0) return -1;
     for (uint32_t i = 0; i < n; ++i) {
         uint64_t id = 0;
-        if (pci(i, &id) != 0) continue;
+        if (g_smi.pci(i, &id) != 0) continue;
         if ((unsigned)(id >> 32) == dom && (unsigned)((id >> 8) & 0xff) == b && (unsigned)((id >> 3) & 0x1f) == d && (unsigned)(id & 7) == f) {
-            g_smi.dv = i;
-            g_smi.state = 1;
-            return;
+            g_smi.dv_of[dev] = (int)i + 1;
+            return (int)i;
         }
     }
+    return -1;
 }
 
 /* bytes of VRAM the driver counts as in use on the current device, INCLUDING memory that was freed but is not wiped yet;
  * -1 when unknown */
 int64_t DflDeviceMemoryInUse(void) {
-    smi_bind();
+    const int dv = smi_device();
     uint64_t used = 0;
-    if (g_smi.state != 1 || g_smi.mem_usage(g_smi.dv, 0 /* RSMI_MEM_TYPE_VRAM */, &used) != 0) return -1;
+    if (dv < 0 || g_smi.mem_usage((uint32_t)dv, 0 /* RSMI_MEM_TYPE_VRAM */, &used) != 0) return -1;
     return (int64_t)used;
 }
 
@@ -91,10 +106,11 @@ int64_t DflDeviceMemoryInUse(void) {
  * and the only one for memory freed inside the running process (that leaves the "in use" figure at once); 0 otherwise or
  * when unknown */
 static int smi_soc_clock_high(void) {
-    SmiFrequencies f;
-    memset(&f, 0, sizeof f);
-    if (g_smi.state != 1 || !g_smi.clk_freq || g_smi.clk_freq(g_smi.dv, 3 /* RSMI_CLK_TYPE_SOC */, &f) != 0 || f.current >= 33) return 0;
-    return f.frequency[f.current] >= 600000000ull;
+    union { SmiFrequencies f; char pad[sizeof(SmiFrequencies) + 256]; } u; /* slack should the library's struct be larger */
+    memset(&u, 0, sizeof u);
+    const int dv = smi_device();
+    if (dv < 0 || !g_smi.clk_freq || g_smi.clk_freq((uint32_t)dv, 3 /* RSMI_CLK_TYPE_SOC */, &u.f) != 0 || u.f.current >= 33) return 0;
+    return u.f.frequency[u.f.current] >= 600000000ull;
 }
 
 /* Blocks while a wipe is in progress -- the "in use" figure FALLING (nothing of ours is being freed meanwhile) or the SOC
@@ -132,10 +148,12 @@ void Init(int argc, char** argv) {
         abort();
     }
     g_initialised = 1;
-    /* a predecessor's memory may still be under the driver's wipe: wait for that before anything is placed */
+    /* a predecessor's memory may still be under the driver's wipe: wait for that before anything is placed -- but briefly by
+       default (5 s; 129 GB take 3.8 s to wipe): on a shared GPU the signs may be another tenant's doing.  DFL_INIT_QUIET_S=0
+       never blocks; INTEGRATION.md documents the wait */
     {
         const char* eq = getenv("DFL_INIT_QUIET_S");
-        const double cap = eq ? atof(eq) : 30.0;
+        const double cap = eq ? atof(eq) : 5.0;
         if (cap > 0.0) {
             const double w = DflWaitDeviceMemoryQuiet(cap);
             if (w > 0.0 && getenv("DFL_WS_VERBOSE")) fprintf(stderr, "[init] waited %.2f s for the driver to finish wiping freed device memory\n", w);
@@ -284,6 +302,22 @@ static void* pool_alloc(size_t bytes) {
     }
     PoolChunk* c = pool_new_chunk(bytes > g_chunk_bytes ? bytes : g_chunk_bytes);
     return c ? pool_take(c, bytes) : NULL;
+}
+
+/* a zero-filled block from the chunks the pool ALREADY holds, NULL when none has room (never reserves a new chunk: the
+ * bounded work-space calibration must not grow the pool for a candidate it may throw away); free with CdamFreeDevice */
+void* DflDevicePoolAllocNoGrow(size_t bytes) {
+    pool_configure();
+    if (g_pool_state != 1 || bytes < POOL_MIN_REQUEST) return NULL;
+    bytes = (bytes + POOL_ALIGN - 1) / POOL_ALIGN * POOL_ALIGN;
+    for (int k = 0; k < g_nchunk; ++k) {
+        void* p = pool_take(&g_chunk[k], bytes);
+        if (p) {
+            HIPGUARD(hipMemsetAsync(p, 0, bytes, g_stream));
+            return p;
+        }
+    }
+    return NULL;
 }
 
 static int pool_free(void* ptr) {

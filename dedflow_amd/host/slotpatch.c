@@ -138,11 +138,44 @@ static index_type find_nz(const index_type* rp, const index_type* ci, index_type
     return lo;
 }
 
+/* The shape limits of tet_lhs_slot_kernel (csrc/k_assemble2.hip) for ONE node patch: slot positions (one lane pair each, two
+ * passes of DFL_SLOT_BLOCK / 2 pairs), tets touching the patch (one lane each in phase 1), trips of a lane pair (a header
+ * byte).  0 = fits; otherwise the reason is written to `why`.  The recursive bisection stops at one node, so a single node
+ * of very high valence (> 256 tets, or a row of > 252 nonzeros) is what can break them -- no cube mesh does, a mesh with a
+ * fan of hundreds of tets around one vertex does.  Host arithmetic only (tests/test_abi_cpu.py calls it without a GPU). */
+static int g_test_pos_limit = 0, g_test_tet_limit = 0;
+/* test hook: lower the limits (0 = the kernel's own) so that an ordinary mesh exercises the refusal and the fall-back */
+void DflSlotPatchSetTestLimits(int positions, int tets) {
+    g_test_pos_limit = positions;
+    g_test_tet_limit = tets;
+}
+int DflSlotPatchLimitCheck(int64_t num_positions, int64_t num_tets, int64_t max_contributions_of_a_position, char* why, size_t why_len) {
+    const int64_t pos_limit = g_test_pos_limit > 0 ? g_test_pos_limit : DFL_SLOT_BLOCK - 1;
+    const int64_t tet_limit = g_test_tet_limit > 0 ? g_test_tet_limit : DFL_SLOT_BLOCK;
+    if (num_positions > pos_limit) {
+        if (why) snprintf(why, why_len, "%lld slot positions in one node patch (limit %lld)", (long long)num_positions, (long long)pos_limit);
+        return 1;
+    }
+    if (num_tets > tet_limit) {
+        if (why) snprintf(why, why_len, "%lld tets touch one node patch (limit %lld)", (long long)num_tets, (long long)tet_limit);
+        return 2;
+    }
+    if ((max_contributions_of_a_position + 1) / 2 > 254) {
+        if (why) snprintf(why, why_len, "%lld contributions to one slot position (limit 508)", (long long)max_contributions_of_a_position);
+        return 3;
+    }
+    return 0;
+}
+
+/* NULL (after a message on stderr) when the mesh breaks a limit of the kernel: the caller falls back to the colored schedule */
 SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, index_type leaf, index_type slot_cap, index_type tet_cap) {
     const index_type T = mesh->num_tet, N = mesh->num_node;
     const index_type* ien = mesh->host->ien;
     const f64* xg = mesh->host->xg;
-    ASSERT((int64_t)T * 16 < 2147483647LL && "slot-patch contribution offsets are 32-bit");
+    if ((int64_t)T * 16 >= 2147483647LL) {
+        fprintf(stderr, "slot-owner schedule: %d tets need 64-bit contribution offsets (limit 134M tets per mesh / rank)\n", T);
+        return NULL;
+    }
     if (tet_cap > DFL_SLOT_BLOCK) tet_cap = DFL_SLOT_BLOCK;       /* one tet per lane in phase 1 (and 12-bit local tet ids in the descriptors) */
     if (slot_cap > DFL_SLOT_BLOCK - 1) slot_cap = DFL_SLOT_BLOCK - 1; /* one slot offset per lane */
     SlotPatchSched* ps = (SlotPatchSched*)CdamMallocHost(SIZE_OF(SlotPatchSched));
@@ -205,25 +238,44 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     int32_t* hdr = (int32_t*)calloc((size_t)P * 8 + 8, sizeof(int32_t));
     int64_t tot_t = 0, tot_s = 0;
     index_type maxt = 0, maxs = 0;
-    for (index_type p = 0; p < P; ++p) {
+    int broken = 0;
+    char why[160] = {0};
+    for (index_type p = 0; p < P && !broken; ++p) {
         int64_t ns = 0; /* slot POSITIONS: one per nodal nonzero + 3 more for every split diagonal slot */
+        int64_t maxc = 0; /* most contributions any position of the patch can receive: its node's valence */
         for (index_type i = x.out[p].lo; i < x.out[p].hi; ++i) {
             ns += rp[idx[i] + 1] - rp[idx[i]];
-            if (vp[idx[i] + 1] - vp[idx[i]] >= SPLIT_MIN) ns += 3;
+            const index_type valence = vp[idx[i] + 1] - vp[idx[i]];
+            if (valence >= SPLIT_MIN) ns += 3;
+            const int64_t c = valence >= SPLIT_MIN ? (valence + 3) / 4 : valence;
+            if (c > maxc) maxc = c;
         }
-        ASSERT(ns <= DFL_SLOT_BLOCK - 1 || x.out[p].hi - x.out[p].lo == 1);
-        ASSERT(nt_of[p] <= 4094 && "slot-patch descriptors hold 12-bit local tet ids (0xFFFF = none)");
+        /* (the bisection honours the caps down to single nodes; a single node can still break the kernel's own limits) */
+        broken = DflSlotPatchLimitCheck(ns, nt_of[p], maxc, why, sizeof why);
+        if (broken) {
+            fprintf(stderr, "slot-owner schedule (assembly schedule 4) cannot hold this mesh: %s, around node %d\n", why, idx[x.out[p].lo]);
+            break;
+        }
         hdr[8 * p + 0] = (int32_t)tot_t;
         hdr[8 * p + 1] = nt_of[p];
         hdr[8 * p + 2] = (int32_t)tot_s;
         hdr[8 * p + 3] = (int32_t)ns;
         tot_t += nt_of[p];
         tot_s += ns;
-        ASSERT(tot_t < 2147483647LL);
         if (nt_of[p] > maxt) maxt = nt_of[p];
         if (ns > maxs) maxs = (index_type)ns;
     }
-    ASSERT(tot_s >= spy->nnz && tot_s < 2147483647LL);
+    if (!broken && (tot_t >= 2147483647LL || tot_s >= 2147483647LL)) {
+        fprintf(stderr, "slot-owner schedule: %lld patch-tet entries / %lld slot positions exceed 32-bit offsets\n", (long long)tot_t, (long long)tot_s);
+        broken = 4;
+    }
+    if (broken) {
+        for (index_type p = 0; p < P; ++p) free(tets_of[p]);
+        free(hdr); free(nt_of); free(tets_of); free(x.out); free(idx); free(ve); free(vp); free(ci); free(rp);
+        CdamFreeHost(ps, SIZE_OF(SlotPatchSched));
+        return NULL;
+    }
+    ASSERT(tot_s >= spy->nnz);
     if (verbose)
         fprintf(stderr, "[slotpatch] %d patches (<= %d nodes / %d slots / %d tets): %.2f tets per patch-tet list entry per tet, max tets %d, "
                         "max slots %d, %.2f s\n", P, leaf, slot_cap, tet_cap, (double)tot_t / (double)(T > 0 ? T : 1), maxt, maxs, omp_get_wtime() - t0);

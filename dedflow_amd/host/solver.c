@@ -207,30 +207,7 @@ void PCDestroy(PC* pc) {
 }
 
 /* ============================== Krylov ================================================== */
-typedef struct KrylovExt {
-    KrylovStats stats;
-    index_type check_interval;
-    b32 check_interval_set; /* KrylovSetCheckInterval was called: PC_TWOLEVEL leaves the interval alone */
-    b32 verbose;
-    DflComm comm;
-    b32 has_comm;
-    PCType pc_type; /* tree KrylovSolve builds: PC_DECOMPOSITION (reference) or PC_ILU0 */
-    index_type restart; /* GMRES(m): basis columns per cycle; <= 0 or >= max_iter = full GMRES (the reference, krylov.c:56-334) */
-    b32 flexible_user; /* KrylovSetFlexible(on): FGMRES whatever the preconditioner; otherwise PC_TWOLEVEL alone switches it on */
-    b32 flexible;   /* FGMRES: keep Z[:,k] = M_k^-1 Q[:,k] (a second basis) so that the preconditioner may vary from step to step */
-    const Mesh3D* mesh; /* optional: node coordinates for preconditioners that aggregate nodes (PC_TWOLEVEL) */
-    index_type agg_size; /* PC_TWOLEVEL: nodes per aggregate */
-    b32 fused_norm; /* partitioned runs: ||w - Qh|| from w.w - sum h^2, one all-reduce per Arnoldi step (off by default) */
-    int q_pooled;   /* the basis Q came from the device pool (placement calibration may pick either kind) */
-    int* d_flag;    /* device int raised by the fused-norm kernel on heavy cancellation */
-    f64* hraw;      /* [ldh] raw CGS coefficients + w.w of the current column (fused update + PC + Givens kernel) */
-    /* cached GMRES work space */
-    index_type ws_n, ws_maxit, ws_hist;
-    int ws_pooled; /* where Q and tmp of the cached work space came from */
-    b32 ws_fresh;  /* the basis was (re)allocated and its placement has not been calibrated yet */
-    f64 *Q, *Z, *H, *tmp, *gv, *beta, *res_hist, *nrm, *work;
-    int64_t work_len;
-} KrylovExt;
+#include "solver_private.h"
 
 static KrylovExt* kext(const Krylov* k) { return (KrylovExt*)k->ext; }
 
@@ -284,26 +261,26 @@ void KrylovSetComm(Krylov* k, const DflComm* comm) {
  * other allocation (0.554 ms with the store compiled out) -- reads of the value array and writes of y compete when both
  * come from one physical neighbourhood.  DFL_KRYLOV_POOL=1 puts them back into the pool (A/B). */
 static int g_ws_pool = -1; /* process default; DflKrylovWorkspaceInPool switches it (developer A/B) */
-static int ws_in_pool(void) {
+int DflWsInPool(void) {
     if (g_ws_pool < 0) { const char* e = getenv("DFL_KRYLOV_POOL"); g_ws_pool = (e && atoi(e) == 1) ? 1 : 0; }
     return g_ws_pool;
 }
 static f64* ws_vec_malloc(ptrdiff_t count) {
-    if (ws_in_pool()) return (f64*)CdamMallocDevice(count * SIZE_OF(f64));
+    if (DflWsInPool()) return (f64*)CdamMallocDevice(count * SIZE_OF(f64));
     void* p = DflVectorArenaAlloc((size_t)count * sizeof(f64));
     if (!p) HIPGUARD(hipMalloc(&p, (size_t)count * sizeof(f64)));
     HIPGUARD(hipMemsetAsync(p, 0, (size_t)count * sizeof(f64), DflStream()));
     return (f64*)p;
 }
 void DflKrylovWorkspaceInPool(int on) { g_ws_pool = on ? 1 : 0; } /* takes effect at the next solve of every solver */
-static void ws_vec_free_as(f64* p, int pooled) {
+void DflWsVecFreeAs(f64* p, int pooled) {
     if (!p) return;
     if (pooled) CdamFreeDevice(p, 0);
     else if (!DflVectorArenaFree(p)) HIPGUARD(hipFree(p));
 }
 
 static void ws_free(KrylovExt* x) {
-    ws_vec_free_as(x->Q, x->q_pooled); ws_vec_free_as(x->Z, x->ws_pooled); CdamFreeDevice(x->H, 0); ws_vec_free_as(x->tmp, x->ws_pooled); CdamFreeDevice(x->gv, 0);
+    DflWsVecFreeAs(x->Q, x->q_pooled); DflWsVecFreeAs(x->Z, x->ws_pooled); CdamFreeDevice(x->H, 0); DflWsVecFreeAs(x->tmp, x->ws_pooled); CdamFreeDevice(x->gv, 0);
     CdamFreeDevice(x->beta, 0); CdamFreeDevice(x->res_hist, 0); CdamFreeDevice(x->nrm, 0); CdamFreeDevice(x->work, 0);
     CdamFreeDevice(x->d_flag, 0);
     CdamFreeDevice(x->hraw, 0);
@@ -315,9 +292,9 @@ static void ws_free(KrylovExt* x) {
 
 /* maxit = basis columns per cycle (the restart length, or max_iter for full GMRES); hist = entries of the residual history */
 static void ws_ensure(KrylovExt* x, index_type n, index_type maxit, index_type ldh, index_type hist) {
-    if (x->ws_n == n && x->ws_maxit == maxit && x->ws_hist >= hist && x->ws_pooled == ws_in_pool()) return;
+    if (x->ws_n == n && x->ws_maxit == maxit && x->ws_hist >= hist && x->ws_pooled == DflWsInPool()) return;
     ws_free(x);
-    x->ws_pooled = ws_in_pool();
+    x->ws_pooled = DflWsInPool();
     x->Q = ws_vec_malloc((ptrdiff_t)n * (maxit + 1));
     x->q_pooled = x->ws_pooled;
     x->H = (f64*)CdamMallocDevice((ptrdiff_t)ldh * maxit * SIZE_OF(f64));
@@ -362,7 +339,7 @@ static b32 jacobi_tree_data(PC* pc, const f64** d33, const f64** d1, index_type*
 }
 
 /* z = M^{-1} (w / *d_nrm), q_out = w / *d_nrm   (d_nrm == NULL: no scaling) */
-static void pc_apply_fused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64* z) {
+void DflPcApplyFused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64* z) {
     index_type N;
     if (pc && pc->type == PC_DECOMPOSITION && decomposition_is_fused_up((PCDecomposition*)pc->data, &N)) {
         PCDecomposition* d = (PCDecomposition*)pc->data;
@@ -378,278 +355,6 @@ static void pc_apply_fused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64*
     if (pc && pc->type == PC_TWOLEVEL) PCTwoLevelSetActiveLength(pc, na);
     if (pc) PCApply(pc, w, z);
     else dfl_dcopy(na, w, z, DflStream());
-}
-
-static char g_cal_log[4096]; /* log of the most recent work-space calibration of this process */
-const char* DflKrylovCalibrationLog(void) { return g_cal_log; }
-
-/* Placement of the basis.  Measured (tools/probe_spmv_r2e.py, profiles/r02_spmv_workspace_candidates.txt): of six
- * identical 2.3 GB basis allocations made one after the other, the FIRST one (it reuses the address range the setup
- * temporaries were freed from) makes every SpMV of the Arnoldi loop that writes into it take 0.70 ms, the other five
- * 0.59 ms -- a property of the allocation, stable over time, independent of where the input vector lies, and invisible to
- * back-to-back SpMV launches (it only shows between the other kernels of the loop).  So when a new basis is allocated for a
- * block-mode matrix, up to DFL_WS_CANDIDATES (default 6, 1 = off) candidates are allocated side by side, a short piece of
- * the real loop (CGS over 6 columns, preconditioner, SpMV into the next column) runs in each with the SpMV timed by
- * hipEvents on the library stream, the fastest candidate is kept and the others are freed.  A few tens of milliseconds
- * once per work-space size; skipped when device memory is short or the basis is tiny. */
-static f64* ws_pick_basis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_t count, index_type na, index_type m, index_type ldh) {
-    int ncand = 6;
-    const char* e = getenv("DFL_WS_CANDIDATES");
-    if (e) ncand = atoi(e);
-    if (ncand > 8) ncand = 8;
-    if (getenv("DFL_VECTOR_ARENA_GB")) ncand = 1;
-    /* (partitioned runs calibrate too: the piece of the loop that is timed is rank-local -- no collective, no halo) */
-    if (ncand < 2 || ws_in_pool() || !MatrixFSBlockValues(A) || m < 8 || na < (1 << 20)) return first;
-    hipStream_t s = DflStream();
-    f64* cand[8];
-    int pooled[8];
-    float best_ms[8];
-    int n = 1;
-    cand[0] = first;
-    pooled[0] = ex->q_pooled;
-    for (; n < ncand; ++n) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (size_t)count * sizeof(f64) + ((size_t)4 << 30)) break;
-        void* p = NULL;
-        /* the second candidate comes from the device pool: which of the two kinds of address range is the slow one
-           differs from process to process (the value array sits in the pool; measured both ways round) */
-        pooled[n] = (n == 1 && !ex->q_pooled && DflDevicePoolEnabled());
-        if (pooled[n]) p = CdamMallocDevice(count * SIZE_OF(f64));
-        else if (n >= 4 && ncand >= 5) {
-            /* candidates 4, 5: far from everything allocated so far -- behind a spacer of a quarter / half of the free
-               memory, released again at once (in whole processes every block near the value array was slow: 0.72 ms, and
-               the far block 0.65 ms) */
-            void* spacer = NULL;
-            if (hipMalloc(&spacer, n == 4 ? free_b / 4 : free_b / 2) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
-            if (hipMalloc(&p, (size_t)count * sizeof(f64)) != hipSuccess) { (void)hipGetLastError(); p = NULL; }
-            if (spacer) HIPGUARD(hipFree(spacer));
-            if (!p) break;
-        } else if (hipMalloc(&p, (size_t)count * sizeof(f64)) != hipSuccess) { (void)hipGetLastError(); break; }
-        HIPGUARD(hipMemsetAsync(p, 0, (size_t)count * sizeof(f64), s));
-        cand[n] = (f64*)p;
-    }
-    if (n == 1) return first;
-    hipEvent_t a, b;
-    HIPGUARD(hipEventCreate(&a));
-    HIPGUARD(hipEventCreate(&b));
-    const f64 one = 1.0;
-    HIPGUARD(hipMemcpyAsync(ex->nrm, &one, sizeof one, H2D, s));
-    HIPGUARD(hipMemsetAsync(ex->H, 0, (size_t)ldh * sizeof(f64), s));
-    int best = 0;
-    /* the SpMV output goes to eight columns spread over the block (a block is not always of one kind from end to end: with
-       three sample columns a candidate scored 0.604 ms and then ran at 0.643 ms); a candidate's score is their mean */
-#define TIME_CANDIDATE(k, out)                                                                       \
-    {                                                                                                \
-        f64* Qk = cand[k];                                                                           \
-        f64* w = Qk + (size_t)6 * (size_t)na;                                                        \
-        float sum_ms = 0.f;                                                                          \
-        for (int rep = 0; rep < 9; ++rep) {                                                          \
-            float ms = 0.f;                                                                          \
-            const index_type col = rep == 0 ? 7 : 7 + (index_type)(((int64_t)(m - 7) * (rep - 1)) / 7); \
-            f64* y = Qk + (size_t)col * (size_t)na;                                                  \
-            dfl_cgs_dots(na, 6, Qk, na, w, ex->H, ex->work, s);                                      \
-            dfl_cgs_update(na, 6, Qk, na, ex->H, w, ex->nrm + 1, 1, ex->work, s);                    \
-            pc_apply_fused(pc, na, w, ex->nrm, ex->tmp);                                             \
-            HIPGUARD(hipEventRecord(a, s));                                                          \
-            MatrixMatVec(A, ex->tmp, y);                                                             \
-            HIPGUARD(hipEventRecord(b, s));                                                          \
-            HIPGUARD(hipEventSynchronize(b));                                                        \
-            HIPGUARD(hipEventElapsedTime(&ms, a, b));                                                \
-            if (rep > 0) sum_ms += ms;                                                               \
-        }                                                                                            \
-        (out) = sum_ms / 8.f;                                                                        \
-    }
-#define TIME_CANDIDATES(out_ms) \
-    for (int k = 0; k < n; ++k) TIME_CANDIDATE(k, out_ms[k])
-    /* Device memory that is freed is wiped by the driver in the background, and while that runs the in-loop SpMV takes
-       0-8 % longer, unevenly (tools/probe_clocks.py: the spacers above are ~250 GB; the SOC clock sits at 1200 MHz instead of
-       < 100 MHz, the idle board draws 50 W more, for 3-4 s after the last free -- whether the GPU works or idles meanwhile).
-       The wipe comes in episodes of 0.15-0.25 s with calm stretches of ~0.5 s in between (rocprofv3 trace of the bench:
-       steps at 0.644 and 0.5965 ms alternating in blocks).  Timing candidates, or handing the work space to a solver, in that
-       state measures the wipe.  So: wait until the driver's "VRAM in use" figure has stopped falling (DflWaitDeviceMemoryQuiet,
-       host/runtime.c: it counts freed memory until it is wiped, ~36 GB/s); without rocm_smi, sample the loop on one candidate
-       every 100 ms until the last twenty samples (2 s) lie within 2.5 % of each other (a calm loop scatters by +-1 % from sample to sample, an episode adds 8 %; at most
-       DFL_WS_SETTLE_S seconds, default 10, 0 = off); once here, before the candidates are compared, and once at the end,
-       after the losers have been freed. */
-    double settle_cap = 10.0;
-    { const char* es = getenv("DFL_WS_SETTLE_S"); if (es) settle_cap = atof(es); }
-    double settled_s[2] = {0.0, 0.0};
-    float settled_ms[2] = {0.f, 0.f};
-#define SETTLE(k, which)                                                                             \
-    if (settle_cap > 0.0 && (settled_s[which] = DflWaitDeviceMemoryQuiet(settle_cap + 20.0)) >= 0.0) {  \
-        TIME_CANDIDATE(k, settled_ms[which]) /* the driver's own figure says the wipe is over */   \
-    } else if (settle_cap > 0.0) {            /* no rocm_smi: judge by the loop itself */         \
-        float hist[20], cur = 0.f;                                                                   \
-        int nh = 0;                                                                                  \
-        const double t_begin = omp_get_wtime();                                                      \
-        for (;;) {                                                                                   \
-            TIME_CANDIDATE(k, cur)                                                                   \
-            hist[nh % 20] = cur;                                                                     \
-            ++nh;                                                                                    \
-            float lo = cur, hi = cur;                                                                \
-            for (int i = 0; i < (nh < 20 ? nh : 20); ++i) {                                          \
-                if (hist[i] < lo) lo = hist[i];                                                      \
-                if (hist[i] > hi) hi = hist[i];                                                      \
-            }                                                                                        \
-            if ((nh >= 20 && hi - lo < 0.025f * lo) || omp_get_wtime() - t_begin > settle_cap) break; \
-            usleep(100000);                                                                          \
-        }                                                                                            \
-        settled_s[which] = omp_get_wtime() - t_begin;                                                \
-        settled_ms[which] = cur;                                                                     \
-    }
-    /* the value array has a placement of its own: whole processes were measured in which the SpMV took 0.67 ms with the
-       array where the allocator's pool put it, whatever the output vector, and 0.57 ms with a plain hipMalloc copy
-       (tools/probe_spmv_r2f.py).  So copies of the values are made -- a plain block, and five behind spacers of between an eighth and
-       five eighths of the free memory (the value array's placement decides more than the basis block's: whole
-       rows of the candidate matrix are fast or slow) -- BEFORE anything is timed (their spacer is the last big free), the same piece of the loop is timed
-       on them too, and the matrix moves if that is at least 3 % faster (DFL_VAL_RELOCATE=0 keeps it where it is). */
-    enum { NV = 6 }; /* value-array copies: a plain block, and blocks behind spacers of 1/3, 1/8, 5/8, 1/4 and 1/2 of the free memory */
-    static const char* const hv_name[NV] = {"plain", "far (1/3)", "far (1/8)", "far (5/8)", "far (1/4)", "far (1/2)"};
-    float moved_ms[NV][8];
-    int moved = 0, moved_tested = 0;
-    void* hv[NV] = {NULL, NULL, NULL, NULL, NULL, NULL};
-    MatrixFS* fs = (MatrixFS*)A->data;
-    f64* const old_val = fs->block_val;
-    {
-        const size_t vbytes = (size_t)fs->spy1x1->nnz * 16 * sizeof(f64);
-        size_t free_b = 0, total_b = 0;
-        const char* ev = getenv("DFL_VAL_RELOCATE");
-        if (!(ev && atoi(ev) == 0) && !fs->block_val_heap && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-            free_b > (NV + 1) * vbytes + ((size_t)4 << 30)) {
-            for (int v = 0; v < NV; ++v) {
-                void* spacer = NULL;
-                if (v >= 1) {
-                    if (ncand < 5) continue; /* DFL_WS_CANDIDATES < 5: no far placements, no spacers */
-                    size_t fb = 0, tb = 0;
-                    if (hipMemGetInfo(&fb, &tb) != hipSuccess || fb < 2 * vbytes + ((size_t)4 << 30)) continue;
-                    const size_t sp = v == 1 ? fb / 3 : v == 2 ? fb / 8 : v == 3 ? fb / 8 * 5 : v == 4 ? fb / 4 : fb / 2;
-                    if (hipMalloc(&spacer, sp) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
-                }
-                if (hipMalloc(&hv[v], vbytes) != hipSuccess) { (void)hipGetLastError(); hv[v] = NULL; }
-                if (spacer) HIPGUARD(hipFree(spacer));
-                if (hv[v]) HIPGUARD(hipMemcpyAsync(hv[v], old_val, vbytes, D2D, s));
-            }
-        }
-    }
-    SETTLE(0, 0)
-    TIME_CANDIDATES(best_ms)
-    for (int k = 1; k < n; ++k)
-        if (best_ms[k] < best_ms[best]) best = k;
-    const int best_in_place = best;
-    const int n_round1 = n;
-    int pooled1[8];
-    void* addr1[8];
-    for (int k = 0; k < 8; ++k) { pooled1[k] = k < n ? pooled[k] : 0; addr1[k] = k < n ? (void*)cand[k] : NULL; }
-    void* const addr_hv[NV] = {hv[0], hv[1], hv[2], hv[3], hv[4], hv[5]};
-    {
-        float hv_best[NV] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
-        int hv_k[NV] = {0, 0, 0, 0, 0, 0};
-        for (int v = 0; v < NV; ++v) {
-            if (!hv[v]) continue;
-            fs->block_val = (f64*)hv[v]; /* timed in place of the original; nothing else runs meanwhile */
-            TIME_CANDIDATES(moved_ms[v])
-            fs->block_val = old_val;
-            moved_tested |= 1 << v;
-            for (int k = 0; k < n; ++k)
-                if (moved_ms[v][k] < hv_best[v]) { hv_best[v] = moved_ms[v][k]; hv_k[v] = k; }
-        }
-        int vb = 0;
-        for (int v = 1; v < NV; ++v)
-            if (hv_best[v] < hv_best[vb]) vb = v;
-        if (hv[vb] && hv_best[vb] < 0.97f * best_ms[best]) {
-            DflMatrixFSRelocateBlockValues(A, (f64*)hv[vb]);
-            best = hv_k[vb];
-            moved = 1 + vb;
-            hv[vb] = NULL;
-        }
-        for (int v = 0; v < NV; ++v)
-            if (hv[v]) HIPGUARD(hipFree(hv[v]));
-    }
-    HIPGUARD(hipStreamSynchronize(s));
-    for (int k = 0; k < n; ++k)
-        if (k != best) ws_vec_free_as(cand[k], pooled[k]);
-    SETTLE(best, 1)
-    /* Second round.  The placement is drawn afresh per allocation, and on a box that has been used the first draw is often
-       poor all round (behind the 50M-tet tests: 0.68-0.72 ms for every candidate in place, 0.636 ms after the value array
-       had moved -- and 0.591 ms for the NEXT work space of the same process, allocated after that move).  So with the
-       value array where it now stays, up to three more blocks are drawn behind spacers of other sizes, timed next to the
-       winner in one quiet stretch, and the fastest of the four is kept (DFL_WS_ROUND2=0 skips it). */
-    float round2_ms[4] = {0.f, 0.f, 0.f, 0.f};
-    int round2_n = 0, round2_pick = 0;
-    {
-        const char* e2 = getenv("DFL_WS_ROUND2");
-        if (ncand >= 5 && !(e2 && atoi(e2) == 0)) {
-            f64* const win = cand[best];
-            const int win_pooled = pooled[best];
-            cand[0] = win;
-            pooled[0] = win_pooled;
-            n = 1;
-            for (int extra = 0; extra < 3; ++extra) {
-                size_t free_b = 0, total_b = 0;
-                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * (size_t)count * sizeof(f64) + ((size_t)4 << 30)) break;
-                void *spacer = NULL, *p2 = NULL;
-                const size_t sp = extra == 0 ? free_b / 8 : extra == 1 ? free_b / 3 : free_b / 8 * 5;
-                if (hipMalloc(&spacer, sp) != hipSuccess) { (void)hipGetLastError(); spacer = NULL; }
-                if (hipMalloc(&p2, (size_t)count * sizeof(f64)) != hipSuccess) { (void)hipGetLastError(); p2 = NULL; }
-                if (spacer) HIPGUARD(hipFree(spacer));
-                if (!p2) break;
-                HIPGUARD(hipMemsetAsync(p2, 0, (size_t)count * sizeof(f64), s));
-                cand[n] = (f64*)p2;
-                pooled[n] = 0;
-                ++n;
-            }
-            if (n > 1) {
-                double keep_s = settled_s[1];
-                SETTLE(0, 1)
-                settled_s[1] += keep_s;
-                TIME_CANDIDATES(round2_ms)
-                round2_n = n;
-                for (int k = 1; k < n; ++k)
-                    if (round2_ms[k] < 0.99f * round2_ms[round2_pick]) round2_pick = k;
-                HIPGUARD(hipStreamSynchronize(s));
-                for (int k = 0; k < n; ++k)
-                    if (k != round2_pick) ws_vec_free_as(cand[k], pooled[k]);
-                keep_s = settled_s[1];
-                SETTLE(round2_pick, 1)
-                settled_s[1] += keep_s;
-            }
-            best = round2_pick;
-        }
-    }
-#undef SETTLE
-#undef TIME_CANDIDATES
-#undef TIME_CANDIDATE
-    HIPGUARD(hipEventDestroy(a));
-    HIPGUARD(hipEventDestroy(b));
-    {   /* what was measured and decided: kept for DflKrylovCalibrationLog (bench.py records it), printed under DFL_WS_VERBOSE */
-        char* o = g_cal_log;
-        size_t left = sizeof g_cal_log;
-        g_cal_log[0] = 0;
-#define LOG(...) do { int w_ = snprintf(o, left, __VA_ARGS__); if (w_ > 0) { size_t u_ = (size_t)w_ < left ? (size_t)w_ : left - 1; o += u_; left -= u_; } } while (0)
-        LOG("[krylov] basis placement: settled after %.2f s at %.4f ms; in-loop SpMV into %d candidates:", settled_s[0], settled_ms[0], n_round1);
-        for (int k = 0; k < n_round1; ++k) LOG(" %.4f%s%s", best_ms[k], pooled1[k] ? "(pool)" : "", k == best_in_place ? "*" : "");
-        LOG(" ms\n");
-        for (int v = 0; v < NV; ++v)
-            if (moved_tested & (1 << v)) {
-                LOG("[krylov] value array on a %s heap copy:", hv_name[v]);
-                for (int k = 0; k < n_round1; ++k) LOG(" %.4f", moved_ms[v][k]);
-                LOG(" ms%s\n", moved == 1 + v ? " -> moved there" : "");
-            }
-        if (round2_n > 1) {
-            LOG("[krylov] second round, winner and %d new far blocks:", round2_n - 1);
-            for (int k = 0; k < round2_n; ++k) LOG(" %.4f%s", round2_ms[k], k == round2_pick ? "*" : "");
-            LOG(" ms\n");
-        }
-        LOG("[krylov] losers freed; settled after %.2f s in all at %.4f ms\n", settled_s[1], settled_ms[1]);
-        LOG("[krylov] addresses: values %p (were %p; copies %p %p %p %p %p %p), first-round blocks", (void*)fs->block_val, (void*)old_val, addr_hv[0], addr_hv[1], addr_hv[2],
-            addr_hv[3], addr_hv[4], addr_hv[5]);
-        for (int k = 0; k < n_round1; ++k) LOG(" %p", addr1[k]);
-        LOG(", tmp %p, kept %p\n", (void*)ex->tmp, (void*)cand[best]);
-#undef LOG
-        if (getenv("DFL_WS_VERBOSE")) fputs(g_cal_log, stderr);
-    }
-    ex->q_pooled = pooled[best];
-    return cand[best]; /* all-zero: only zero vectors went through the kernels above */
 }
 
 /* partitioned runs: the local dot products cover ghost rows too, so those must be zero in every Krylov vector (SpMV and
@@ -683,6 +388,7 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     index_type total = 0; /* iterations over all cycles */
     const index_type n_interior = dist ? ex->comm.num_interior_node : 0;
     const b32 split_rows = dist && n_interior > 0 && MatrixFSBlockValues(A) && n_interior <= MatrixFSOwnedRows(A);
+    const b32 side_rows_off = getenv("DFL_NO_SIDE_BOUNDARY_ROWS") != NULL; /* A/B: boundary rows on the library stream */
 
     ws_ensure(ex, n, m, ldh, maxit);
     /* active length: [0,4N) if the matrix is the block-mode (u,p) system and b's tail is zero (Q5) */
@@ -697,7 +403,7 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     }
     if (ex->ws_fresh) {
         ex->ws_fresh = FALSE;
-        if (!ex->flexible) ex->Q = ws_pick_basis(ex, A, pc, ex->Q, (ptrdiff_t)n * (m + 1), na, m, ldh);
+        if (!ex->flexible && !ex->no_calibration) ex->Q = DflWsPickBasis(ex, A, pc, ex->Q, (ptrdiff_t)n * (m + 1), na, m, ldh);
     }
     if (ex->flexible && !ex->Z) ex->Z = ws_vec_malloc((ptrdiff_t)n * m);
     f64* const Zb = ex->flexible ? ex->Z : NULL;
@@ -761,14 +467,24 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
         while (!converged && iter < m && total < maxit) {
             /* 2.0 tmp = inv(P) Q[:,iter]   2.2 Q[:,iter+1] = A tmp */
             f64* const zk = Zb ? ZCOL(iter) : tmp; /* FGMRES keeps every preconditioned vector */
-            if (!z_ready) DFL_TIMED(DFL_TAG_PC, pc_apply_fused(pc, na, QCOL(iter), ex->nrm + iter, zk));
+            if (!z_ready) DFL_TIMED(DFL_TAG_PC, DflPcApplyFused(pc, na, QCOL(iter), ex->nrm + iter, zk));
             if (dist && split_rows) {
                 /* interior rows read no ghost entry: they run while the halo is in flight */
                 if (ex->comm.halo_begin) ex->comm.halo_begin(ex->comm.ctx, zk);
                 else ex->comm.halo_exchange(ex->comm.ctx, zk);
                 DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, zk, QCOL(iter + 1), 0, n_interior));
-                if (ex->comm.halo_begin) ex->comm.halo_end(ex->comm.ctx, zk);
-                DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, zk, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A)));
+                hipStream_t side = (ex->comm.halo_begin && ex->comm.halo_stream && !side_rows_off) ? ex->comm.halo_stream(ex->comm.ctx) : NULL;
+                if (side) {
+                    /* the boundary rows go behind the unpack on the exchange's own stream: they write rows the interior launch
+                       does not touch and read ghost entries it does not read, so the two overlap; halo_end joins both */
+                    DflSetStream(side);
+                    MatrixFSMatVecRange(A, zk, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A));
+                    DflSetStream(s);
+                    ex->comm.halo_end(ex->comm.ctx, zk);
+                } else {
+                    if (ex->comm.halo_begin) ex->comm.halo_end(ex->comm.ctx, zk);
+                    DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, zk, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A)));
+                }
             } else {
                 if (dist) ex->comm.halo_exchange(ex->comm.ctx, zk);
                 DFL_TIMED(DFL_TAG_SPMV, MatrixMatVec(A, zk, QCOL(iter + 1)));
@@ -828,7 +544,7 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
                 dfl_daxpy(na, 1.0, tmp, x, s);
             } else {
                 dfl_gemv_n(na, iter, Q, na, ex->beta, tmp, s);
-                pc_apply_fused(pc, na, tmp, NULL, tmp + n);
+                DflPcApplyFused(pc, na, tmp, NULL, tmp + n);
                 dfl_daxpy(na, 1.0, tmp + n, x, s);
             }
         }
@@ -941,25 +657,35 @@ void KrylovDestroy(Krylov* ksp) {
     CdamFreeHost(ksp, SIZE_OF(Krylov));
 }
 
-/* KrylovSolve, krylov.c:386-456: (re)build the PC tree when the matrix changes, PCSetup every solve */
-void KrylovSolve(Krylov* ksp, Matrix* A, f64* x, f64* b) {
+/* the (re)build step of KrylovSolve, krylov.c:386-456: a new PC tree when there is none or the matrix changed */
+PC* DflKrylovBuildPC(Krylov* ksp, Matrix* A) {
     PC* pc = (PC*)ksp->pc;
     if (pc == NULL || pc->mat != A) {
         PCDestroy(pc);
+        /* PC_TWOLEVEL needs the block-mode matrix, the mesh (node coordinates for the aggregates) and, on a partitioned
+           matrix, a communicator that knows its rank; when it cannot be built the solver falls back to PC_ILU0 (block mode) or
+           to the reference's tree -- on every rank alike, the conditions are properties of the setup, not of the data */
+        KrylovExt* kx = kext(ksp);
+        pc = NULL;
+        if (kx->pc_type == PC_TWOLEVEL && MatrixFSBlockValues(A) && kx->mesh)
+            pc = PCCreateTwoLevelDist(A, kx->mesh, kx->agg_size, kx->has_comm ? &kx->comm : NULL);
+        const b32 two_level = pc != NULL;
+        if (kx->pc_type == PC_TWOLEVEL && !two_level)
+            fprintf(stderr, "KrylovSolve: PC_TWOLEVEL unavailable for this matrix, using %s\n",
+                    MatrixFSBlockValues(A) ? "PC_ILU0" : "the reference's Jacobi tree");
         /* convergence test every 20th iteration (krylov.c:281) -- every 4th under PC_TWOLEVEL, where an iteration costs two
            fine-level matvecs, a DILU sweep and a coarse solve and the 8-byte read nothing -- unless the caller chose */
-        const b32 two_level = kext(ksp)->pc_type == PC_TWOLEVEL && MatrixFSBlockValues(A) && kext(ksp)->mesh;
-        if (!kext(ksp)->check_interval_set) kext(ksp)->check_interval = two_level ? 4 : 20;
+        if (!kx->check_interval_set) kx->check_interval = two_level ? 4 : 20;
         /* the coarse level of PC_TWOLEVEL is solved by an inner Krylov iteration: the PC varies, the outer solver must be
            flexible; a fixed preconditioner gets the plain recurrence back (and its Z basis freed) unless the caller asked */
-        kext(ksp)->flexible = two_level || kext(ksp)->flexible_user;
-        if (!kext(ksp)->flexible && kext(ksp)->Z) {
-            ws_vec_free_as(kext(ksp)->Z, kext(ksp)->ws_pooled);
-            kext(ksp)->Z = NULL;
+        kx->flexible = two_level || kx->flexible_user;
+        if (!kx->flexible && kx->Z) {
+            DflWsVecFreeAs(kx->Z, kx->ws_pooled);
+            kx->Z = NULL;
         }
-        if (kext(ksp)->pc_type == PC_TWOLEVEL && MatrixFSBlockValues(A) && kext(ksp)->mesh) {
-            pc = PCCreateTwoLevel(A, kext(ksp)->mesh, kext(ksp)->agg_size);
-        } else if (kext(ksp)->pc_type == PC_ILU0 && MatrixFSBlockValues(A)) {
+        if (two_level) {
+            /* built above */
+        } else if ((kx->pc_type == PC_ILU0 || kx->pc_type == PC_TWOLEVEL) && MatrixFSBlockValues(A)) {
             pc = PCCreateDILU(A);
         } else if (A->type == MAT_TYPE_FS && ((MatrixFS*)A->data)->n_offset >= 4) {
             MatrixFS* fs = (MatrixFS*)A->data;
@@ -978,10 +704,35 @@ void KrylovSolve(Krylov* ksp, Matrix* A, f64* x, f64* b) {
         }
         ksp->pc = pc;
     }
+    return pc;
+}
+
+/* KrylovSolve, krylov.c:386-456: (re)build the PC tree when the matrix changes, PCSetup every solve */
+void KrylovSolve(Krylov* ksp, Matrix* A, f64* x, f64* b) {
+    PC* pc = DflKrylovBuildPC(ksp, A);
     DflRangePush("KrylovSolve");
     PCSetup(pc);
     DflKrylovSolvePrepared(ksp, A, x, b);
     DflRangePop();
+}
+
+void DflKrylovMarkInner(Krylov* ksp) { kext(ksp)->no_calibration = TRUE; }
+
+/* the GMRES work space for this matrix as the next KrylovSolve would size it (host/ws_placement.c calibrates it ahead of
+   the first solve) */
+static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx);
+b32 DflKrylovEnsureWorkspace(Krylov* ksp, Matrix* A, index_type* n_out, index_type* m_out, index_type* ldh_out) {
+    KrylovExt* ex = kext(ksp);
+    if (ksp->ksp_solve != GMRESSolvePrivate) return FALSE;
+    const index_type maxit = ksp->max_iter;
+    const index_type m = (ex->restart > 0 && ex->restart < maxit) ? ex->restart : maxit;
+    const index_type n = MatrixNumRow(A);
+    const index_type ldh = CEIL_DIV(m + 1, 32) * 32;
+    ws_ensure(ex, n, m, ldh, maxit);
+    *n_out = n;
+    *m_out = m;
+    *ldh_out = ldh;
+    return TRUE;
 }
 
 /* the solve alone: ksp->pc exists and has been set up for the current values of A (inner solvers of PC_TWOLEVEL, whose

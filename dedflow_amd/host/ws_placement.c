@@ -1,0 +1,379 @@
+/* Placement of the Krylov work space (and, on request only, of the block value array).
+ *
+ * What is known ("SpMV placement"): the in-loop block-CSR SpMV of a 10M-tet system takes 0.59 ms or
+ * 0.67-0.72 ms depending on WHICH device allocations hold its output column and the value array -- a static property of
+ * the pair of allocations, a deterministic function of the layout that no virtual-address property predicts; plus a
+ * transient 0-8 % while the driver wipes freed memory.  Two forms of defence:
+ *
+ *   DflWsPickBasis (default, inside the first KrylovSolve that allocates a basis): BOUNDED and side-effect free.  At most
+ *     four candidate blocks (the one already allocated, one from the allocator's pool, two more plain blocks), no spacers,
+ *     no copy of the value array, no relocation of anything the caller may hold a pointer to, no waiting on the driver; extra
+ *     device memory <= min(DFL_WS_MAX_EXTRA_GB (16), a quarter of the free memory), wall time < 1 s (a few tens of
+ *     milliseconds of loop pieces).  Skipped for inner / coarse solvers, small systems, pooled or arena work spaces.
+ *
+ *   DflKrylovCalibratePlacement (explicit opt-in; bench.py calls it before its timed legs and says so in `config`): the heavy
+ *     lottery of round 2 -- six basis blocks, two of them behind spacers, up to six heap copies of the value array behind
+ *     spacers of 1/8 ... 5/8 of the free memory, a second round of three more far blocks, waits for the driver's wipe around
+ *     the timings -- now capped by `max_extra_bytes` of transient device memory.  It MAY move the block value array
+ *     (DFL_VAL_RELOCATE=0 forbids): a host that cached MatrixFSBlockValues(A) must ask again afterwards.
+ *
+ * Both time the same thing: a short piece of the real Arnoldi loop (CGS over 6 columns, preconditioner, SpMV into the next
+ * column; the SpMV between hipEvents on the library stream) with the output going to eight columns spread over the block. */
+#include <math.h>
+#include <string.h>
+#include <unistd.h>
+#include <omp.h>
+#include "dedflow.h"
+#include "dedflow_kernels.h"
+#include "host_private.h"
+#include "solver_private.h"
+
+static char g_cal_log[4096]; /* log of the most recent calibration of this process (either form) */
+const char* DflKrylovCalibrationLog(void) { return g_cal_log; }
+
+typedef struct LogBuf { char* o; size_t left; } LogBuf;
+static void log_begin(LogBuf* l) { l->o = g_cal_log; l->left = sizeof g_cal_log; g_cal_log[0] = 0; }
+static void log_add(LogBuf* l, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+#include <stdarg.h>
+static void log_add(LogBuf* l, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    int w = vsnprintf(l->o, l->left, fmt, ap);
+    va_end(ap);
+    if (w > 0) {
+        size_t u = (size_t)w < l->left ? (size_t)w : l->left - 1;
+        l->o += u;
+        l->left -= u;
+    }
+}
+
+/* what the timing needs from the solver */
+typedef struct Loop {
+    KrylovExt* ex;
+    Matrix* A;
+    PC* pc;
+    index_type na, m, ldh;
+    hipEvent_t a, b;
+} Loop;
+
+static void loop_open(Loop* L, KrylovExt* ex, Matrix* A, PC* pc, index_type na, index_type m, index_type ldh) {
+    L->ex = ex; L->A = A; L->pc = pc; L->na = na; L->m = m; L->ldh = ldh;
+    HIPGUARD(hipEventCreate(&L->a));
+    HIPGUARD(hipEventCreate(&L->b));
+    const f64 one = 1.0;
+    HIPGUARD(hipMemcpyAsync(ex->nrm, &one, sizeof one, H2D, DflStream()));
+    HIPGUARD(hipMemsetAsync(ex->H, 0, (size_t)ldh * sizeof(f64), DflStream()));
+}
+static void loop_close(Loop* L) {
+    HIPGUARD(hipEventDestroy(L->a));
+    HIPGUARD(hipEventDestroy(L->b));
+}
+
+/* mean in-loop SpMV time (ms) with the output in block Qk: one untimed pass, then eight columns spread over the block (a
+ * block is not always of one kind from end to end: with three sample columns a candidate scored 0.604 ms and ran at 0.643) */
+static float time_block(const Loop* L, f64* Qk) {
+    KrylovExt* ex = L->ex;
+    hipStream_t s = DflStream();
+    const index_type na = L->na, m = L->m;
+    f64* w = Qk + (size_t)6 * (size_t)na;
+    float sum_ms = 0.f;
+    for (int rep = 0; rep < 9; ++rep) {
+        float ms = 0.f;
+        const index_type col = rep == 0 ? 7 : 7 + (index_type)(((int64_t)(m - 7) * (rep - 1)) / 7);
+        f64* y = Qk + (size_t)col * (size_t)na;
+        dfl_cgs_dots(na, 6, Qk, na, w, ex->H, ex->work, s);
+        dfl_cgs_update(na, 6, Qk, na, ex->H, w, ex->nrm + 1, 1, ex->work, s);
+        DflPcApplyFused(L->pc, na, w, ex->nrm, ex->tmp);
+        HIPGUARD(hipEventRecord(L->a, s));
+        MatrixMatVec(L->A, ex->tmp, y);
+        HIPGUARD(hipEventRecord(L->b, s));
+        HIPGUARD(hipEventSynchronize(L->b));
+        HIPGUARD(hipEventElapsedTime(&ms, L->a, L->b));
+        if (rep > 0) sum_ms += ms;
+    }
+    return sum_ms / 8.f;
+}
+
+static b32 eligible(const KrylovExt* ex, Matrix* A, index_type na, index_type m) {
+    if (ex->no_calibration || getenv("DFL_VECTOR_ARENA_GB") || DflWsInPool()) return FALSE;
+    return MatrixFSBlockValues(A) != NULL && m >= 8 && na >= (1 << 20);
+}
+
+static void* try_malloc(size_t bytes) {
+    void* p = NULL;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return NULL; }
+    return p;
+}
+
+/* ---- default: bounded, no side effects beyond the choice of the basis block ------------------------------------------ */
+f64* DflWsPickBasis(KrylovExt* ex, Matrix* A, PC* pc, f64* first, ptrdiff_t count, index_type na, index_type m, index_type ldh) {
+    int ncand = 4;
+    const char* e = getenv("DFL_WS_CANDIDATES");
+    if (e) ncand = atoi(e);
+    if (ncand > 4) ncand = 4; /* more draws, spacers and value-array copies: DflKrylovCalibratePlacement */
+    if (ncand < 2 || !eligible(ex, A, na, m)) return first;
+    const double t_begin = omp_get_wtime();
+    hipStream_t s = DflStream();
+    const size_t bytes = (size_t)count * sizeof(f64);
+    size_t budget = (size_t)16 << 30;
+    if (getenv("DFL_WS_MAX_EXTRA_GB")) budget = (size_t)(atof(getenv("DFL_WS_MAX_EXTRA_GB")) * 1073741824.0);
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return first; }
+        if (free_b / 4 < budget) budget = free_b / 4;
+    }
+    f64* cand[4];
+    int pooled[4];
+    float ms[4];
+    int n = 1;
+    cand[0] = first;
+    pooled[0] = ex->q_pooled;
+    size_t used = 0;
+    for (; n < ncand && used + bytes <= budget; ++n) {
+        /* the second candidate comes from the device pool: which of the two kinds of address range is the slow one differs
+           from process to process (the value array sits in the pool; measured both ways round) */
+        void* p = (n == 1 && !ex->q_pooled) ? DflDevicePoolAllocNoGrow(bytes) : NULL; /* room in a chunk already reserved */
+        pooled[n] = p != NULL;
+        if (!p) p = try_malloc(bytes);
+        if (!p) break;
+        if (!pooled[n]) HIPGUARD(hipMemsetAsync(p, 0, bytes, s));
+        cand[n] = (f64*)p;
+        used += bytes;
+    }
+    if (n == 1) return first;
+    Loop L;
+    loop_open(&L, ex, A, pc, na, m, ldh);
+    int best = 0;
+    for (int k = 0; k < n; ++k) {
+        ms[k] = time_block(&L, cand[k]);
+        if (ms[k] < ms[best]) best = k;
+    }
+    loop_close(&L);
+    HIPGUARD(hipStreamSynchronize(s));
+    for (int k = 0; k < n; ++k)
+        if (k != best) DflWsVecFreeAs(cand[k], pooled[k]);
+    LogBuf lg;
+    log_begin(&lg);
+    log_add(&lg, "[krylov] basis placement (default, bounded): in-loop SpMV into %d candidates:", n);
+    for (int k = 0; k < n; ++k) log_add(&lg, " %.4f%s%s", ms[k], pooled[k] ? "(pool)" : "", k == best ? "*" : "");
+    log_add(&lg, " ms; %.2f GB of extra device memory for %.3f s, value array untouched\n", (double)used / 1073741824.0,
+            omp_get_wtime() - t_begin);
+    if (getenv("DFL_WS_VERBOSE")) fputs(g_cal_log, stderr);
+    ex->q_pooled = pooled[best];
+    return cand[best]; /* all-zero: only zero vectors went through the kernels above */
+}
+
+/* ---- explicit heavy form --------------------------------------------------------------------------------------------- */
+typedef struct Budget { size_t cap, used; } Budget; /* transient device memory this call may hold at any one time */
+
+static size_t budget_left(const Budget* b) { return b->cap > b->used ? b->cap - b->used : 0; }
+
+/* a block of `bytes` allocated behind a spacer of `frac` of the free memory (0: no spacer); the spacer is released at once.
+ * Spacer and block together stay inside the budget: the spacer shrinks to what is left. */
+static void* alloc_far(Budget* bud, size_t bytes, double frac) {
+    if (budget_left(bud) < bytes) return NULL;
+    void* spacer = NULL;
+    if (frac > 0.0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return NULL; }
+        if (free_b < 2 * bytes + ((size_t)4 << 30)) return NULL;
+        size_t sp = (size_t)((double)free_b * frac);
+        if (sp > budget_left(bud) - bytes) sp = budget_left(bud) - bytes;
+        if (sp >= ((size_t)64 << 20)) spacer = try_malloc(sp);
+    }
+    void* p = try_malloc(bytes);
+    if (spacer) HIPGUARD(hipFree(spacer));
+    if (p) bud->used += bytes;
+    return p;
+}
+
+/* wait for the driver's background wipe of freed memory to end (DflWaitDeviceMemoryQuiet); without rocm_smi judge by the
+ * loop itself: sample one block every 100 ms until twenty samples (2 s) lie within 2.5 % of each other.  Returns seconds. */
+static double settle(const Loop* L, f64* Qk, double cap, float* ms_out) {
+    if (cap <= 0.0) { *ms_out = 0.f; return 0.0; }
+    double waited = DflWaitDeviceMemoryQuiet(cap + 20.0);
+    if (waited >= 0.0) { *ms_out = time_block(L, Qk); return waited; }
+    float hist[20], cur = 0.f;
+    int nh = 0;
+    const double t0 = omp_get_wtime();
+    for (;;) {
+        cur = time_block(L, Qk);
+        hist[nh % 20] = cur;
+        ++nh;
+        float lo = cur, hi = cur;
+        for (int i = 0; i < (nh < 20 ? nh : 20); ++i) {
+            if (hist[i] < lo) lo = hist[i];
+            if (hist[i] > hi) hi = hist[i];
+        }
+        if ((nh >= 20 && hi - lo < 0.025f * lo) || omp_get_wtime() - t0 > cap) break;
+        usleep(100000);
+    }
+    *ms_out = cur;
+    return omp_get_wtime() - t0;
+}
+
+enum { NB = 8, NV = 6 };
+static const char* const hv_name[NV] = {"plain", "far (1/3)", "far (1/8)", "far (5/8)", "far (1/4)", "far (1/2)"};
+static const double hv_frac[NV] = {0.0, 1.0 / 3.0, 0.125, 0.625, 0.25, 0.5};
+
+void DflKrylovCalibratePlacement(Krylov* ksp, Matrix* A, int64_t max_extra_bytes) {
+    KrylovExt* ex = (KrylovExt*)ksp->ext;
+    if (!ex || !MatrixFSBlockValues(A)) return;
+    index_type n = 0, m = 0, ldh = 0;
+    if (!DflKrylovEnsureWorkspace(ksp, A, &n, &m, &ldh)) return; /* not a GMRES solver */
+    PC* pc = DflKrylovBuildPC(ksp, A);
+    PCSetup(pc);
+    const index_type N = ((MatrixFS*)A->data)->spy1x1->num_row;
+    const index_type na = n == 6 * N ? 4 * N : n; /* the driver path: the phi / T tail of b is zero (Q5) */
+    ex->ws_fresh = FALSE;                          /* the first solve does not calibrate again */
+    if (ex->flexible || !eligible(ex, A, na, m)) return;
+    hipStream_t s = DflStream();
+    const ptrdiff_t count = (ptrdiff_t)n * (m + 1);
+    const size_t bytes = (size_t)count * sizeof(f64);
+    Budget bud = {max_extra_bytes > 0 ? (size_t)max_extra_bytes : ~(size_t)0, 0};
+    double settle_cap = 10.0;
+    if (getenv("DFL_WS_SETTLE_S")) settle_cap = atof(getenv("DFL_WS_SETTLE_S"));
+    const double t_begin = omp_get_wtime();
+
+    /* 1. basis candidates: the block in place, one from the pool, two plain, two behind spacers of 1/4 and 1/2 */
+    f64* cand[NB];
+    int pooled[NB];
+    float ms[NB];
+    int nc = 1;
+    cand[0] = ex->Q;
+    pooled[0] = ex->q_pooled;
+    for (; nc < 6; ++nc) {
+        pooled[nc] = (nc == 1 && !ex->q_pooled && DflDevicePoolEnabled());
+        void* p = NULL;
+        if (pooled[nc]) { if (budget_left(&bud) >= bytes) { p = CdamMallocDevice(count * SIZE_OF(f64)); bud.used += bytes; } }
+        else p = alloc_far(&bud, bytes, nc == 4 ? 0.25 : nc == 5 ? 0.5 : 0.0);
+        if (!p) break;
+        if (!pooled[nc]) HIPGUARD(hipMemsetAsync(p, 0, bytes, s));
+        cand[nc] = (f64*)p;
+    }
+    /* 2. copies of the value array (its placement decides more than the basis block's: whole rows of the candidate matrix
+          are fast or slow), made BEFORE anything is timed -- their spacers are the last big frees */
+    MatrixFS* fs = (MatrixFS*)A->data;
+    f64* const old_val = fs->block_val;
+    const size_t vbytes = (size_t)fs->spy1x1->nnz * 16 * sizeof(f64);
+    void* hv[NV] = {NULL, NULL, NULL, NULL, NULL, NULL};
+    const char* ev = getenv("DFL_VAL_RELOCATE");
+    const b32 may_move = !(ev && atoi(ev) == 0) && !fs->block_val_heap;
+    if (may_move)
+        for (int v = 0; v < NV; ++v) {
+            hv[v] = alloc_far(&bud, vbytes, hv_frac[v]);
+            if (hv[v]) HIPGUARD(hipMemcpyAsync(hv[v], old_val, vbytes, D2D, s));
+        }
+    Loop L;
+    loop_open(&L, ex, A, pc, na, m, ldh);
+    /* 3. quiet, then the candidate matrix */
+    float settled_ms[2] = {0.f, 0.f};
+    double settled_s[2] = {0.0, 0.0};
+    settled_s[0] = settle(&L, cand[0], settle_cap, &settled_ms[0]);
+    int best = 0;
+    for (int k = 0; k < nc; ++k) {
+        ms[k] = time_block(&L, cand[k]);
+        if (ms[k] < ms[best]) best = k;
+    }
+    const int best_in_place = best, n_round1 = nc;
+    float moved_ms[NV][NB];
+    float hv_best[NV];
+    int hv_k[NV], moved = 0;
+    for (int v = 0; v < NV; ++v) {
+        hv_best[v] = 1e30f;
+        hv_k[v] = 0;
+        if (!hv[v]) continue;
+        fs->block_val = (f64*)hv[v]; /* timed in place of the original; nothing else runs meanwhile */
+        for (int k = 0; k < nc; ++k) {
+            moved_ms[v][k] = time_block(&L, cand[k]);
+            if (moved_ms[v][k] < hv_best[v]) { hv_best[v] = moved_ms[v][k]; hv_k[v] = k; }
+        }
+        fs->block_val = old_val;
+    }
+    unsigned tested = 0;
+    for (int v = 0; v < NV; ++v)
+        if (hv[v]) tested |= 1u << v;
+    {
+        int vb = 0;
+        for (int v = 1; v < NV; ++v)
+            if (hv_best[v] < hv_best[vb]) vb = v;
+        if (hv[vb] && hv_best[vb] < 0.97f * ms[best]) { /* at least 3 % faster: the matrix moves */
+            DflMatrixFSRelocateBlockValues(A, (f64*)hv[vb]);
+            best = hv_k[vb];
+            moved = 1 + vb;
+            hv[vb] = NULL;
+        }
+        for (int v = 0; v < NV; ++v)
+            if (hv[v]) { HIPGUARD(hipFree(hv[v])); bud.used -= vbytes; }
+    }
+    HIPGUARD(hipStreamSynchronize(s));
+    for (int k = 0; k < nc; ++k)
+        if (k != best) { DflWsVecFreeAs(cand[k], pooled[k]); if (k) bud.used -= bytes; }
+    {
+        float tmp_ms;
+        settled_s[1] = settle(&L, cand[best], settle_cap, &tmp_ms);
+        settled_ms[1] = tmp_ms;
+    }
+    /* 4. second round: with the value array where it now stays, three more blocks behind spacers of other sizes next to the
+          winner (on a box that has been used the first draw is often poor all round); DFL_WS_ROUND2=0 skips it */
+    float r2_ms[4] = {0.f, 0.f, 0.f, 0.f};
+    int r2_n = 0, r2_pick = 0;
+    f64* win = cand[best];
+    int win_pooled = pooled[best];
+    if (!(getenv("DFL_WS_ROUND2") && atoi(getenv("DFL_WS_ROUND2")) == 0)) {
+        static const double r2_frac[3] = {0.125, 1.0 / 3.0, 0.625};
+        f64* c2[4];
+        int p2[4];
+        c2[0] = win;
+        p2[0] = win_pooled;
+        int n2 = 1;
+        for (int extra = 0; extra < 3; ++extra) {
+            void* p = alloc_far(&bud, bytes, r2_frac[extra]);
+            if (!p) break;
+            HIPGUARD(hipMemsetAsync(p, 0, bytes, s));
+            c2[n2] = (f64*)p;
+            p2[n2] = 0;
+            ++n2;
+        }
+        if (n2 > 1) {
+            float tmp_ms;
+            settled_s[1] += settle(&L, c2[0], settle_cap, &tmp_ms);
+            for (int k = 0; k < n2; ++k) {
+                r2_ms[k] = time_block(&L, c2[k]);
+                if (k && r2_ms[k] < 0.99f * r2_ms[r2_pick]) r2_pick = k;
+            }
+            r2_n = n2;
+            HIPGUARD(hipStreamSynchronize(s));
+            for (int k = 0; k < n2; ++k)
+                if (k != r2_pick) DflWsVecFreeAs(c2[k], p2[k]);
+            win = c2[r2_pick];
+            win_pooled = p2[r2_pick];
+            settled_s[1] += settle(&L, win, settle_cap, &tmp_ms);
+            settled_ms[1] = tmp_ms;
+        }
+    }
+    loop_close(&L);
+    ex->Q = win;
+    ex->q_pooled = win_pooled;
+    /* 5. what was measured and decided */
+    LogBuf lg;
+    log_begin(&lg);
+    log_add(&lg, "[krylov] basis placement (explicit calibration, cap %.1f GB): settled after %.2f s at %.4f ms; in-loop SpMV into %d candidates:",
+            max_extra_bytes > 0 ? (double)max_extra_bytes / 1073741824.0 : INFINITY, settled_s[0], settled_ms[0], n_round1);
+    for (int k = 0; k < n_round1; ++k) log_add(&lg, " %.4f%s%s", ms[k], pooled[k] ? "(pool)" : "", k == best_in_place ? "*" : "");
+    log_add(&lg, " ms\n");
+    for (int v = 0; v < NV; ++v)
+        if (tested & (1u << v)) {
+            log_add(&lg, "[krylov] value array on a %s heap copy:", hv_name[v]);
+            for (int k = 0; k < n_round1; ++k) log_add(&lg, " %.4f", moved_ms[v][k]);
+            log_add(&lg, " ms%s\n", moved == 1 + v ? " -> moved there" : "");
+        }
+    if (r2_n > 1) {
+        log_add(&lg, "[krylov] second round, winner and %d new far blocks:", r2_n - 1);
+        for (int k = 0; k < r2_n; ++k) log_add(&lg, " %.4f%s", r2_ms[k], k == r2_pick ? "*" : "");
+        log_add(&lg, " ms\n");
+    }
+    log_add(&lg, "[krylov] losers freed; settled after %.2f s in all at %.4f ms; %.1f s wall; values %p (were %p), basis %p\n", settled_s[1],
+            settled_ms[1], omp_get_wtime() - t_begin, (void*)fs->block_val, (void*)old_val, (void*)win);
+    if (getenv("DFL_WS_VERBOSE")) fputs(g_cal_log, stderr);
+}

@@ -167,3 +167,31 @@ def dem_particles(P: int, radius: float, seed_x: int = 11, seed_v: int = 12):
     x = np.random.default_rng(seed_x).uniform(0.0, 1.0, size=(P, 3))
     v = np.random.default_rng(seed_v).normal(0.0, 0.1, size=(P, 3))
     return np.ascontiguousarray(x.reshape(-1)), np.ascontiguousarray(v.reshape(-1)), radius
+
+
+def fan_mesh(num_surface: int = 40, seed: int = 5) -> TetMesh:
+    """A ball of tets around ONE central vertex: `num_surface` points on the unit sphere, their convex hull triangulated
+    (2 V - 4 triangles), every triangle joined to the centre.  The central vertex is shared by 2 V - 4 tets -- V = 40 gives
+    76, more than the 64 conflict-free classes of the compact assembly schedule, with a nodal row of V + 1 = 41 nonzeros
+    (inside the reference's 64 per row, csr.c:10) and 76 JPL colors (inside its 256).  Boundary group 0 = the whole surface,
+    groups 1-5 empty."""
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(seed)
+    p = rng.normal(size=(num_surface, 3))
+    p /= np.linalg.norm(p, axis=1)[:, None]
+    p *= rng.uniform(0.8, 1.0, size=(num_surface, 1))   # not all on one sphere: breaks symmetry, still star-shaped
+    hull = ConvexHull(p / np.linalg.norm(p, axis=1)[:, None])
+    tri = hull.simplices.astype(np.int64)
+    xg = np.vstack([np.zeros((1, 3)), p])               # node 0 = the centre
+    tets = np.column_stack([np.zeros(len(tri), np.int64), tri + 1])
+    x = xg[tets]
+    vol = np.einsum("ij,ij->i", np.cross(x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]), x[:, 3] - x[:, 0])
+    flip = vol < 0
+    tets[flip, 2], tets[flip, 3] = tets[flip, 3].copy(), tets[flip, 2].copy()
+    nf = len(tets)
+    surf = np.arange(1, num_surface + 1, dtype=np.int32)
+    return TetMesh(M=0, xg=np.ascontiguousarray(xg.reshape(-1)), ien=np.ascontiguousarray(tets.reshape(-1).astype(np.int32)),
+                   bound_node_offset=np.array([0] + [num_surface] * 6, np.int32), bound_node=surf,
+                   bound_elem_offset=np.array([0] + [nf] * 6, np.int32),
+                   bound_ien=np.ascontiguousarray(tets[:, 1:].reshape(-1).astype(np.int32)),
+                   bound_f2e=np.arange(nf, dtype=np.int32), bound_forn=np.zeros(nf, np.int32))

@@ -387,6 +387,13 @@ const f64* PCDILUGetInverseBlocks(PC* pc);
  * PCSetup), Ac^-1 by a few inner Jacobi-GMRES iterations (rtol 0.1) -- hence the outer solver runs as FGMRES.  Iteration
  * counts become (nearly) independent of the mesh size: 50M tets converge in tens of iterations instead of ~600. */
 PC* PCCreateTwoLevel(Matrix* mat, const Mesh3D* mesh, index_type agg_size);
+/* the same on an element-partitioned matrix (owned rows first, MatrixFSSetOwnedRows): every rank aggregates the nodes it
+ * owns, the Galerkin coarse matrix is assembled from the owned rows and REPLICATED (its values all-reduced at PCSetup, the
+ * restricted residual all-reduced per application: one halo exchange + one all-reduce of 4 Nc doubles per apply), every rank
+ * solves the same small coarse problem, the smoother is the rank-local DILU.  `comm` (copied) must carry rank / world;
+ * NULL = PCCreateTwoLevel.  Collective: every rank of the partition calls it, and PCSetup / PCApply, together. */
+struct DflComm;
+PC* PCCreateTwoLevelDist(Matrix* mat, const Mesh3D* mesh, index_type agg_size, const struct DflComm* comm);
 void PCTwoLevelSetActiveLength(PC* pc, index_type n_active);
 void PCTwoLevelSetInner(PC* pc, index_type max_iter, f64 rtol); /* inner coarse solve: default 40 iterations, rtol 0.1 */
 void PCTwoLevelInfo(PC* pc, index_type* num_aggregate, index_type* coarse_nnz, int64_t* inner_iterations);
@@ -455,6 +462,13 @@ typedef struct DflComm {
     void (*halo_begin)(void* ctx, f64* d_x);
     void (*halo_end)(void* ctx, f64* d_x);
     index_type num_interior_node;
+    /* this process's place in the partition (0 / 0 when the implementer does not say: preconditioners that need a global
+     * numbering -- PC_TWOLEVEL on a partitioned matrix -- then refuse and KrylovSolve falls back to PC_ILU0) */
+    int rank, world;
+    /* optional: the stream the exchange started by halo_begin runs on (NULL / returns NULL: synchronous).  The Krylov matvec
+     * enqueues the boundary rows there, behind the unpack, so that they overlap the interior rows on the library stream and
+     * the library stream waits once (in halo_end) for both */
+    hipStream_t (*halo_stream)(void* ctx);
 } DflComm;
 void KrylovSetComm(Krylov* krylov, const DflComm* comm);
 const DflComm* KrylovGetComm(const Krylov* krylov); /* NULL on a single GPU */
@@ -468,7 +482,10 @@ int DflRcclLoad(const char* path);
 int DflRcclUniqueIdBytes(void);
 int DflRcclGetUniqueId(char* out_bytes);
 DflRcclComm* DflRcclCommCreate(const char* id_bytes, int rank, int world);
-void DflRcclCommCreateHaloComm(DflRcclComm* c, const char* id_bytes); /* optional own communicator for the halo stream */
+/* optional own communicator for the halo stream; 0 = created.  If it fails on ANY rank, every rank must call
+ * DflRcclCommDropHaloComm (agree on the result first): mixed use pairs sends and receives of different communicators */
+int DflRcclCommCreateHaloComm(DflRcclComm* c, const char* id_bytes);
+void DflRcclCommDropHaloComm(DflRcclComm* c);
 void DflRcclCommSetInterior(DflRcclComm* c, index_type n_interior); /* owned nodes [0, n_interior) touch no ghost */
 void DflRcclCommSetHalo(DflRcclComm* c, index_type n_local, index_type n_owned, const index_type* send_count,
                         const index_type* send_idx, const index_type* recv_count, const index_type* recv_idx);
@@ -507,6 +524,14 @@ int64_t DflDeviceMemoryInUse(void);
 /* text log of this process's most recent Krylov work-space calibration (host/solver.c: what every candidate placement
  * measured, what was chosen, how long the waits were); "" when none has run.  DFL_WS_VERBOSE=1 prints the same to stderr. */
 const char* DflKrylovCalibrationLog(void);
+/* Placement of the Krylov work space (host/ws_placement.c).  The first KrylovSolve that allocates a GMRES basis for a large
+ * block-mode system times at most four candidate blocks and keeps the fastest: bounded (<= 16 GB or a quarter of the free
+ * memory extra, < 1 s), nothing the caller can see moves (DFL_WS_CANDIDATES=1 switches even that off).  This call is the
+ * explicit, heavy form: builds the solver's preconditioner and work space for A now and draws many more placements -- basis
+ * blocks and heap copies of the block value array behind spacers of up to 5/8 of the free memory, waiting for the driver's
+ * memory wipe around the timings (5-15 s) -- holding at most max_extra_bytes of transient device memory (<= 0: no cap).  It
+ * MAY move the block value array: ask MatrixFSBlockValues(A) again afterwards (DFL_VAL_RELOCATE=0 forbids the move). */
+void DflKrylovCalibratePlacement(Krylov* krylov, Matrix* A, int64_t max_extra_bytes);
 double DflWaitDeviceMemoryQuiet(double max_seconds);
 /* boundary group whose faces get the weak-BC terms of AssembleSystemTetFace (default 4 = the reference's hard-coded group,
  * assemble.cu:1826-1828); lists are rebuilt when the group changes */

@@ -686,15 +686,22 @@ void orc_priorities_from_u32(const uint32_t* raw, i32 T, i32* prio) {
 // seen while deciding maxima (Q1).
 i32 orc_color_jpl(const i32* ien, i32 T, i32 N, const i32* v2e_row, const i32* v2e_col, i32* color, i32 max_color,
                   i32 tie_break_by_index, i32* num_ties) {
+    // One round = ColorElementJPLKernel over every element, then ReverseColorKernel / SetUpFlagKernel (synchronous: a round
+    // reads the colors of the previous one).  Colored elements return at once in the kernel (ec < 0), so only the still
+    // uncolored ones are visited here -- an `active` list compacted after each round, same result -- and the visits of a
+    // round are independent of each other (OpenMP over the list; orc_set_threads(1) = serial).
     const i32 MARK = INT32_MAX / 2 + 1;
-    std::vector<i32> nxt(T);
-    i32 ties = 0, c = 0;
-    bool left = true;
-    for (; c < max_color && left; ++c) {
-        for (i32 i = 0; i < T; ++i) {
-            i32 ec = color[i];
-            nxt[i] = ec;
-            if (ec < 0) continue;
+    std::vector<i32> active(T), nxt(T);
+    for (i32 i = 0; i < T; ++i) active[i] = i;
+    i32 nact = T;
+    long long ties = 0;
+    i32 c = 0;
+    for (; c < max_color && nact > 0; ++c) {
+        long long round_ties = 0;
+#pragma omp parallel for schedule(static) reduction(+ : round_ties)
+        for (i32 q = 0; q < nact; ++q) {
+            const i32 i = active[q];
+            const i32 ec = color[i];
             bool found_max = true;
             for (int j = 0; j < 4; ++j) {
                 i32 node = ien[(size_t)i * 4 + j];
@@ -705,22 +712,55 @@ i32 orc_color_jpl(const i32* ien, i32 T, i32 N, const i32* v2e_row, const i32* v
                     if (oc < 0) continue;
                     if (ec < oc) found_max = false;
                     else if (ec == oc) {
-                        ++ties;
+                        ++round_ties;
                         if (tie_break_by_index && i < el) found_max = false;
                     }
                 }
             }
-            if (found_max) nxt[i] = MARK;
+            nxt[q] = found_max ? MARK : ec;
         }
-        left = false;
-        for (i32 i = 0; i < T; ++i) {
-            if (nxt[i] == MARK) color[i] = -1 - c;  // ReverseColorKernel
-            if (color[i] >= 0) left = true;         // SetUpFlagKernel + cub Max
+        ties += round_ties;
+        i32 keep = 0;
+        for (i32 q = 0; q < nact; ++q) {
+            const i32 i = active[q];
+            if (nxt[q] == MARK) color[i] = -1 - c;  // ReverseColorKernel
+            else active[keep++] = i;                 // SetUpFlagKernel + cub Max: anything left?
         }
+        nact = keep;
     }
     for (i32 i = 0; i < T; ++i) color[i] = color[i] * (-1) - 1;  // RecoverColorKernel
-    if (num_ties) *num_ties = ties;
+    if (num_ties) *num_ties = (i32)(ties > INT32_MAX ? INT32_MAX : ties);
+    (void)N;
     return c;
+}
+
+// The same coloring without the rounds (bench.py's cpu_baseline set-up at 10M tets, where 141 rounds over every uncolored
+// element take minutes): an element becomes a local maximum among its uncolored neighbours in the round after its last
+// BLOCKING neighbour was colored -- blocking = strictly higher priority (color_impl.cu:87: `ec < color[elem]`), or equal
+// priority and higher index under the tie break -- so color(i) = 1 + max color over its blocking neighbours (0 without any),
+// evaluated in descending (priority, index) order `order[T]`.  Checked against orc_color_jpl in tests/test_oracle_cpu.py.
+i32 orc_color_jpl_sorted(const i32* ien, i32 T, const i32* v2e_row, const i32* v2e_col, const i32* prio, const i32* order,
+                         i32* color, i32 tie_break_by_index) {
+    i32 num_color = 0;
+    for (i32 q = 0; q < T; ++q) {
+        const i32 i = order[q];
+        const i32 pi = prio[i];
+        i32 c = 0;
+        for (int j = 0; j < 4; ++j) {
+            const i32 node = ien[(size_t)i * 4 + j];
+            for (i32 k = v2e_row[node]; k < v2e_row[node + 1]; ++k) {
+                const i32 el = v2e_col[k];
+                if (el == i) continue;
+                const i32 pe = prio[el];
+                if (pe > pi || (pe == pi && tie_break_by_index && el > i)) {
+                    if (color[el] + 1 > c) c = color[el] + 1;
+                }
+            }
+        }
+        color[i] = c;
+        if (c + 1 > num_color) num_color = c + 1;
+    }
+    return num_color;
 }
 
 // per-color batches: src/Mesh.c:165-206, src/indexing.cu:92-102 (count + stable copy_if)

@@ -105,6 +105,22 @@ def color_jpl(ien, T, N, prio=None, tie_break=False, max_color=256):
     return color, int(nc), int(ties.value)
 
 
+def color_jpl_sorted(ien, T, N, prio=None, tie_break=False):
+    """The same coloring by one pass in descending priority order (orc_color_jpl_sorted): set-up of bench.py's 10M-tet
+    cpu_baseline leg.  Returns (color, num_color)."""
+    if prio is None:
+        prio = priorities(T)
+    prio = np.ascontiguousarray(prio, dtype=np.int32)
+    row, col = v2e(ien, T, N)
+    idx = np.arange(T, dtype=np.int32)
+    order = np.ascontiguousarray(np.lexsort((idx, prio))[::-1].astype(np.int32))   # descending (priority, index)
+    color = np.zeros(T, np.int32)
+    f = lib().orc_color_jpl_sorted
+    f.restype = C.c_int
+    nc = f(_p(ien), C.c_int(T), _p(row), _p(col), _p(prio), _p(order), _p(color), C.c_int(1 if tie_break else 0))
+    return color, int(nc)
+
+
 def batches(color, num_color):
     T = color.size
     off = np.empty(num_color + 1, np.int32)
@@ -136,7 +152,7 @@ class System:
     """The reference's setup sequence (src/main.c:372-413) on the CPU: nodal
     pattern, three expanded patterns, JPL coloring, color batches."""
 
-    def __init__(self, mesh, tie_break=False, prio=None):
+    def __init__(self, mesh, tie_break=False, prio=None, sorted_coloring=False):
         self.mesh = mesh
         self.N = mesh.num_node
         self.T = mesh.num_tet
@@ -145,7 +161,11 @@ class System:
         self.rp33, self.ci33 = csr_expand(self.rp11, self.ci11, 3, 3)
         self.rp31, self.ci31 = csr_expand(self.rp11, self.ci11, 3, 1)
         self.rp13, self.ci13 = csr_expand(self.rp11, self.ci11, 1, 3)
-        self.color, self.num_color, self.num_ties = color_jpl(mesh.ien, self.T, self.N, prio=prio, tie_break=tie_break)
+        if sorted_coloring:   # one pass instead of num_color rounds, same colors (bench.py's 10M-tet CPU leg)
+            self.color, self.num_color = color_jpl_sorted(mesh.ien, self.T, self.N, prio=prio, tie_break=tie_break)
+            self.num_ties = None
+        else:
+            self.color, self.num_color, self.num_ties = color_jpl(mesh.ien, self.T, self.N, prio=prio, tie_break=tie_break)
         self.batch_offset, self.batch_ind = batches(self.color, self.num_color)
 
     def new_values(self):

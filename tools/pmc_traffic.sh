@@ -9,7 +9,7 @@ REPO=$PWD
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $REPO/$OUT/$c -o pmc --output-format csv -- python3 $REPO/bench.py --M $M --steps 1 --warmup 0 --gmres-its 6 --cpu-M 0 --dem-particles 0 --solve-to-rtol 0 > $REPO/$OUT/$c.log 2>&1 || { echo "pass $c failed"; tail -5 $REPO/$OUT/$c.log; exit 1; }
+  rocprofv3 --kernel-trace --pmc $c -d $REPO/$OUT/$c -o pmc --output-format csv -- python3 $REPO/bench.py --M $M --steps 1 --warmup 0 --gmres-its 6 --cpu-M 0 --dem-particles 0 --solve-to-rtol 0 --placement default > $REPO/$OUT/$c.log 2>&1 || { echo "pass $c failed"; tail -5 $REPO/$OUT/$c.log; exit 1; }
 done
 cd $REPO
 python3 - $OUT $M <<'PY'
