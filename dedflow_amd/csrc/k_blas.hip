@@ -383,6 +383,103 @@ __global__ __launch_bounds__(BLK) void cgs_update_pc_kernel(I nrows, I N, I ncol
     }
 }
 
+// The same step with TWO owned nodes per thread: nodes 2t and 2t + 1 are six consecutive velocity rows (three 16-byte
+// loads per basis column, 16-byte aligned: the column stride 4N doubles and 6t doubles are both multiples of two) and two
+// consecutive pressure rows (one 16-byte load, 8-byte aligned when N is odd) -- the node-per-thread form above streams the
+// basis with 8-byte loads (5.0 TB/s at 227k owned nodes).  REVERSE walks the basis columns from the newest to the oldest:
+// the dots pass before it read them oldest to newest, so the columns it touched last (still in the 256 MiB Infinity Cache
+// when the whole basis no longer fits) are read first.  Same arithmetic per row except for the order of the column sum.
+typedef double d2a8 __attribute__((ext_vector_type(2), aligned(8)));
+template <bool REVERSE>
+__global__ __launch_bounds__(BLK) void cgs_update_pc2_kernel(I nrows, I N, I ncol, const T* __restrict__ Q, long long ldq,
+                                                            const T* __restrict__ hraw, T* __restrict__ w,
+                                                            const T* __restrict__ dinv33, const T* __restrict__ dinv1,
+                                                            T* __restrict__ z, I iter, T* H, I ldh, T* gv, T* beta, T* res_hist,
+                                                            T* d_nrm, int* d_flag) {
+    __shared__ double sh[GIV_MAX + 2];
+    __shared__ double s_col[GIV_MAX], s_gv[2 * GIV_MAX];
+    __shared__ double s_nrm;
+    for (int j = threadIdx.x; j < ncol + 1 && j < GIV_MAX + 2; j += BLK) sh[j] = hraw[j];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ww = sh[ncol];
+        double hh = 0.0;
+        for (I j = 0; j < ncol; ++j) hh += sh[j] * sh[j];
+        double r = ww - hh;
+        if (r < 1e-6 * ww) {
+            if (d_flag && blockIdx.x == 0) *d_flag = 1;
+            if (r < 0.0) r = 0.0;
+        }
+        s_nrm = sqrt(r);
+    }
+    __syncthreads();
+    const double nrm = s_nrm;
+    const long long i0 = 2 * ((long long)blockIdx.x * BLK + threadIdx.x);
+    if (i0 + 1 < nrows) {
+        const T* wu = w + 3 * i0;
+        const T* wp = w + 3LL * N + i0;
+        d2s u0 = *reinterpret_cast<const d2s*>(wu), u1 = *reinterpret_cast<const d2s*>(wu + 2), u2 = *reinterpret_cast<const d2s*>(wu + 4);
+        d2a8 pp = *reinterpret_cast<const d2a8*>(wp);
+#pragma unroll 4
+        for (int jj = 0; jj < ncol; ++jj) {
+            const int j = REVERSE ? ncol - 1 - jj : jj;
+            const double h = sh[j];
+            const T* q = Q + (long long)j * ldq;
+            const d2s q0 = __builtin_nontemporal_load(reinterpret_cast<const d2s*>(q + 3 * i0));
+            const d2s q1 = __builtin_nontemporal_load(reinterpret_cast<const d2s*>(q + 3 * i0 + 2));
+            const d2s q2 = __builtin_nontemporal_load(reinterpret_cast<const d2s*>(q + 3 * i0 + 4));
+            const d2a8 qp = __builtin_nontemporal_load(reinterpret_cast<const d2a8*>(q + 3LL * N + i0));
+            u0 -= q0 * h; u1 -= q1 * h; u2 -= q2 * h;
+            pp.x -= qp.x * h; pp.y -= qp.y * h;
+        }
+        const double s = 1.0 / nrm;
+        u0 *= s; u1 *= s; u2 *= s; pp.x *= s; pp.y *= s;
+        *reinterpret_cast<d2s*>(w + 3 * i0) = u0;
+        *reinterpret_cast<d2s*>(w + 3 * i0 + 2) = u1;
+        *reinterpret_cast<d2s*>(w + 3 * i0 + 4) = u2;
+        *reinterpret_cast<d2a8*>(w + 3LL * N + i0) = pp;
+        const T* A = dinv33 + i0 * 9;  // node 2t: (u0.x, u0.y, u1.x); node 2t + 1: (u1.y, u2.x, u2.y)
+        d2s z0, z1, z2;
+        z0.x = A[0] * u0.x + A[3] * u0.y + A[6] * u1.x;
+        z0.y = A[1] * u0.x + A[4] * u0.y + A[7] * u1.x;
+        z1.x = A[2] * u0.x + A[5] * u0.y + A[8] * u1.x;
+        z1.y = A[9] * u1.y + A[12] * u2.x + A[15] * u2.y;
+        z2.x = A[10] * u1.y + A[13] * u2.x + A[16] * u2.y;
+        z2.y = A[11] * u1.y + A[14] * u2.x + A[17] * u2.y;
+        *reinterpret_cast<d2s*>(z + 3 * i0) = z0;
+        *reinterpret_cast<d2s*>(z + 3 * i0 + 2) = z1;
+        *reinterpret_cast<d2s*>(z + 3 * i0 + 4) = z2;
+        d2a8 zp;
+        zp.x = pp.x * dinv1[i0];
+        zp.y = pp.y * dinv1[i0 + 1];
+        *reinterpret_cast<d2a8*>(z + 3LL * N + i0) = zp;
+    } else if (i0 < nrows) {  // the odd last node
+        const long long i = i0;
+        double a0 = w[3 * i], a1 = w[3 * i + 1], a2 = w[3 * i + 2], ap = w[3LL * N + i];
+        for (int jj = 0; jj < ncol; ++jj) {
+            const int j = REVERSE ? ncol - 1 - jj : jj;
+            const double h = sh[j];
+            const T* q = Q + (long long)j * ldq;
+            a0 -= q[3 * i] * h; a1 -= q[3 * i + 1] * h; a2 -= q[3 * i + 2] * h; ap -= q[3LL * N + i] * h;
+        }
+        const double s = 1.0 / nrm;
+        a0 *= s; a1 *= s; a2 *= s; ap *= s;
+        w[3 * i] = a0; w[3 * i + 1] = a1; w[3 * i + 2] = a2; w[3LL * N + i] = ap;
+        const T* A = dinv33 + i * 9;
+        z[3 * i + 0] = A[0] * a0 + A[3] * a1 + A[6] * a2;
+        z[3 * i + 1] = A[1] * a0 + A[4] * a1 + A[7] * a2;
+        z[3 * i + 2] = A[2] * a0 + A[5] * a1 + A[8] * a2;
+        z[3LL * N + i] = ap * dinv1[i];
+    }
+    if (blockIdx.x == 0) {  // uniform per block: the barriers inside givens_step_block are safe
+        T* col = H + (long long)iter * ldh;
+        for (int j = threadIdx.x; j < ncol; j += BLK) col[j] = sh[j];
+        if (threadIdx.x == 0) d_nrm[0] = nrm;
+        __syncthreads();
+        givens_step_block(iter, nrm, H, ldh, gv, beta, res_hist, s_col, s_gv);
+    }
+}
+
 // H[0:m,0:m] y = beta by back substitution (cublasDtrsv, krylov.c:297-301), one workgroup: column-oriented so that every
 // step is one coalesced column update (a single thread walking rows pays a dependent global load per entry: 85 us at m = 40)
 template <bool STAGED>
@@ -658,8 +755,23 @@ void dfl_gmres_givens_sq(I iter, T* d_nrm_sq, T* d_H, I ldh, T* d_gv, T* d_beta,
 void dfl_cgs_update_pc_givens(I nrows, I N, I ncol, const T* Q, int64_t ldq, const T* d_hraw, T* w, const T* dinv33, const T* dinv1,
                               T* z, I iter, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, T* d_nrm, int* d_flag, void* stream) {
     if (ncol + 1 > GIV_MAX + 2 || nrows <= 0) abort();  // the caller falls back to the separate kernels beyond GIV_MAX columns
-    cgs_update_pc_kernel<<<ceil_div(nrows, BLK), BLK, 0, S(stream)>>>(nrows, N, ncol, Q, ldq, d_hraw, w, dinv33, dinv1, z, iter, d_H, ldh,
-                                                                      d_gv, d_beta, d_res_hist, d_nrm, d_flag);
+    // DFL_UPDATE_PC: 0 = one node per thread (default), 1 = two nodes per thread (16-byte loads), 2 = + newest column first.
+    // Measured on rank 0 / rank 4 of the 8-way 10M-tet partition (gpurun_out/r3c, profiles/r03_rank_local_*): 7.99 / 7.39 ms
+    // per step with 0, 8.09 / 7.51 with 1, 8.11 / 7.51 with 2 -- at 227k owned nodes the two-node form leaves 1.7 waves per
+    // SIMD, and the wider loads do not make up for the lost memory-level parallelism; the column order changes nothing (the
+    // rank's basis streams from HBM either way).  The wide forms stay for A/B.
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("DFL_UPDATE_PC"); variant = e ? atoi(e) : 0; }
+    const int grid2 = (int)ceil_div((nrows + 1) / 2, BLK);
+    if (variant == 0)
+        cgs_update_pc_kernel<<<ceil_div(nrows, BLK), BLK, 0, S(stream)>>>(nrows, N, ncol, Q, ldq, d_hraw, w, dinv33, dinv1, z, iter, d_H, ldh,
+                                                                          d_gv, d_beta, d_res_hist, d_nrm, d_flag);
+    else if (variant == 1)
+        cgs_update_pc2_kernel<false><<<grid2, BLK, 0, S(stream)>>>(nrows, N, ncol, Q, ldq, d_hraw, w, dinv33, dinv1, z, iter, d_H, ldh, d_gv,
+                                                                   d_beta, d_res_hist, d_nrm, d_flag);
+    else
+        cgs_update_pc2_kernel<true><<<grid2, BLK, 0, S(stream)>>>(nrows, N, ncol, Q, ldq, d_hraw, w, dinv33, dinv1, z, iter, d_H, ldh, d_gv,
+                                                                  d_beta, d_res_hist, d_nrm, d_flag);
     DFL_LAUNCH_CHECK();
 }
 void dfl_gmres_givens_pythagoras(I iter, T* d_nrm, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, int* d_flag, void* stream) {

@@ -167,7 +167,16 @@ DflRcclComm* DflRcclCommCreate(const char* id128, int rank, int world) {
     c->recv_count = (index_type*)CdamMallocHost(SIZE_OF(index_type) * world);
     memset(c->send_count, 0, sizeof(index_type) * (size_t)world);
     memset(c->recv_count, 0, sizeof(index_type) * (size_t)world);
-    HIPGUARD(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    {   /* the halo stream gets the HIGHEST priority: (1) halo traffic and the boundary rows behind it are the latency-critical
+           part of a matvec and should not queue behind the interior rows' workgroups; (2) streams of the default priority
+           share a handful of hardware queues with the library (null) stream -- when the side stream landed on the library
+           stream's own queue, its kernels ran AFTER the interior rows instead of beside them and both hops cost 10 us
+           instead of 6 (rocprofv3 trace of rank 0 vs rank 4 of the 8-way partition, profiles/r03_rank_local_trace.txt) */
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        if (getenv("DFL_HALO_STREAM_DEFAULT_PRIORITY")) hi = 0;
+        HIPGUARD(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
+    }
     /* both events order work of ONE device across two of its streams (x complete -> pack; unpack -> boundary rows): no
        system-scope fence needed -- the peers' data arrives through RCCL's own kernels -- and without it the record / wait
        pair costs less idle time on the library stream (DFL_EVENT_SYSTEM_FENCE=1 restores the default) */

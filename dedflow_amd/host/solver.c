@@ -281,7 +281,8 @@ void DflWsVecFreeAs(f64* p, int pooled) {
 
 static void ws_free(KrylovExt* x) {
     DflWsVecFreeAs(x->Q, x->q_pooled); DflWsVecFreeAs(x->Z, x->ws_pooled); CdamFreeDevice(x->H, 0); DflWsVecFreeAs(x->tmp, x->ws_pooled); CdamFreeDevice(x->gv, 0);
-    CdamFreeDevice(x->beta, 0); CdamFreeDevice(x->res_hist, 0); CdamFreeDevice(x->nrm, 0); CdamFreeDevice(x->work, 0);
+    CdamFreeDevice(x->beta, 0); CdamFreeDevice(x->res_hist, 0); CdamFreeDevice(x->nrm_base, 0); CdamFreeDevice(x->work, 0);
+    x->nrm_base = NULL;
     CdamFreeDevice(x->d_flag, 0);
     CdamFreeDevice(x->hraw, 0);
     x->d_flag = NULL;
@@ -303,7 +304,15 @@ static void ws_ensure(KrylovExt* x, index_type n, index_type maxit, index_type l
     x->beta = (f64*)CdamMallocDevice(((ptrdiff_t)maxit + 1) * SIZE_OF(f64));
     x->res_hist = (f64*)CdamMallocDevice(((ptrdiff_t)hist + 1) * SIZE_OF(f64));
     x->ws_hist = hist;
-    x->nrm = (f64*)CdamMallocDevice(((ptrdiff_t)maxit + 2) * SIZE_OF(f64));
+    /* four slots in front of nrm[]: the operand probes of a solve (tail of b, x), so that probes and ||r0|| = nrm[0] reach the
+       host in one copy */
+    x->nrm_base = (f64*)CdamMallocDevice(((ptrdiff_t)maxit + 2 + 4) * SIZE_OF(f64));
+    x->nrm = x->nrm_base + 4;
+    if (!x->h_stat) {
+        HIPGUARD(hipHostMalloc((void**)&x->h_stat, 16 * sizeof(f64), hipHostMallocDefault));
+        HIPGUARD(hipEventCreateWithFlags(&x->ev_stat, hipEventDisableTiming));
+    }
+    x->assume_valid = FALSE;
     x->work_len = dfl_cgs_work_size(n, maxit + 1) + dfl_reduce_work_size();
     x->work = (f64*)CdamMallocDevice((ptrdiff_t)x->work_len * SIZE_OF(f64));
     x->d_flag = (int*)CdamMallocDevice(16);
@@ -369,8 +378,31 @@ static void zero_ghost_rows(const KrylovExt* ex, Matrix* A, f64* v, index_type n
         HIPGUARD(hipMemsetAsync(v + (size_t)sec * N + no, 0, (size_t)(N - no) * sizeof(f64), s));
 }
 
+/* Host reads without idling the GPU ("lazy" mode: quiet solver, no restarts).  The reference synchronises two to three times
+ * per iteration; round 2 was down to: operand probe, ||r0||, one read per convergence check, two at the end -- each of them a
+ * round trip during which the device sits idle (40-120 us; 0.38 ms of a rank's 8 ms step at 8 ranks).  Now:
+ *   - the operand probe (tail of b zero? x0 zero?) is ASSUMED to answer what it answered in this solver's previous solve;
+ *     the probe still runs, asynchronously, and its result travels with ||r0|| in the first host read of the solve.  A wrong
+ *     assumption that would change the result (tail not zero after all, x0 not zero after all) is noticed there, before x
+ *     has been touched, and the solve is redone with a synchronous probe (gmres_run returns TRUE);
+ *   - a convergence check is enqueued as an asynchronous copy behind iteration k and READ after iteration k + 1 has been
+ *     enqueued: the device works on k + 1 while the host looks at k.  On convergence iteration k + 1 is simply not counted:
+ *     it has written column k + 1 of H, beta[k + 1 ..] and Q[:, k + 2], none of which the update with k + 1 columns reads;
+ *   - a check that falls on the last iteration of the loop, the history and the cancellation flag share the one
+ *     synchronisation at the end.
+ * Verbose solvers print the reference's lines in the reference's order and keep the eager reads; so do restarted solves
+ * (their cycle boundaries read the true residual anyway).  DFL_KRYLOV_EAGER_SYNC=1 forces the eager form (A/B). */
+static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe);
 static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     Krylov* ksp = (Krylov*)ctx;
+    if (gmres_run(A, x, b, ksp, FALSE)) {
+        const b32 again = gmres_run(A, x, b, ksp, TRUE);
+        ASSERT(!again);
+        UNUSED(again);
+    }
+}
+
+static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe) {
     KrylovExt* ex = kext(ksp);
     PC* pc = (PC*)ksp->pc;
     hipStream_t s = DflStream();
@@ -391,14 +423,32 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     const b32 side_rows_off = getenv("DFL_NO_SIDE_BOUNDARY_ROWS") != NULL; /* A/B: boundary rows on the library stream */
 
     ws_ensure(ex, n, m, ldh, maxit);
+    const b32 lazy = !ex->verbose && m >= maxit && getenv("DFL_KRYLOV_EAGER_SYNC") == NULL;
     /* active length: [0,4N) if the matrix is the block-mode (u,p) system and b's tail is zero (Q5) */
     index_type na = n;
-    b32 x_is_zero = FALSE;
+    b32 x_is_zero = FALSE, tail_zero = FALSE;
+    b32 first_read_done = !lazy; /* ||r0|| on the host (and the assumed probe answers verified) */
+    b32 assumed = FALSE;         /* the probe answers of this solve are last solve's, still to be verified */
+    const b32 up_system = MatrixFSBlockValues(A) && n == 6 * ((MatrixFS*)A->data)->spy1x1->num_row;
+    const index_type tail_begin = up_system ? 4 * (n / 6) : n;
     {
-        b32 tail_zero = FALSE;
-        const b32 up_system = MatrixFSBlockValues(A) && n == 6 * ((MatrixFS*)A->data)->spy1x1->num_row;
         /* partitioned runs keep the matvec: every rank has to take the same path through the halo exchange */
-        probe_operands(b, up_system ? 4 * (n / 6) : n, n, dist ? NULL : x, ex->work, &tail_zero, &x_is_zero);
+        const f64* xp = dist ? NULL : x;
+        if (lazy && ex->assume_valid && !force_probe) {
+            tail_zero = ex->assume_tail_zero;
+            x_is_zero = xp ? ex->assume_x_zero : FALSE;
+            /* the probes themselves, asynchronously, into the slots in front of nrm[] */
+            if (n > tail_begin) dfl_dnrm2(n - tail_begin, b + tail_begin, ex->nrm_base, ex->work, s);
+            else HIPGUARD(hipMemsetAsync(ex->nrm_base, 0, sizeof(f64), s));
+            if (xp) dfl_dnrm2(n, xp, ex->nrm_base + 1, ex->work, s);
+            else HIPGUARD(hipMemsetAsync(ex->nrm_base + 1, 0, sizeof(f64), s));
+            assumed = TRUE;
+        } else {
+            probe_operands(b, tail_begin, n, xp, ex->work, &tail_zero, &x_is_zero);
+            ex->assume_valid = TRUE;
+            ex->assume_tail_zero = tail_zero;
+            ex->assume_x_zero = x_is_zero;
+        }
         if (up_system && tail_zero) na = 4 * (n / 6);
     }
     if (ex->ws_fresh) {
@@ -415,6 +465,40 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
 #define HCOL(c) (H + (size_t)(c) * (size_t)ldh)
     ex->stats.converged = FALSE;
     ex->stats.iterations = 0;
+    /* FIRST_READ: probes + ||r0|| to the host (one copy of the five doubles in front of / at nrm[0]), synchronously -- used
+       where nothing has been read yet and the host needs ||r0|| now (before x is first updated).  FIRST_RESOLVE digests them:
+       a wrong assumption that matters -> return TRUE (redo); r0 = 0 -> nothing to do (x solves the system). */
+#define FIRST_RESOLVE()                                                                                         \
+    do {                                                                                                        \
+        rnrm_init = ex->h_stat[4];                                                                              \
+        ex->stats.rnrm_init = rnrm_init;                                                                        \
+        first_read_done = TRUE;                                                                                 \
+        if (assumed) {                                                                                          \
+            const b32 tz = ex->h_stat[0] == 0.0, xz = dist ? FALSE : ex->h_stat[1] == 0.0;                      \
+            const b32 wrong = (tail_zero && !tz) || (x_is_zero && !xz);                                         \
+            ex->assume_tail_zero = tz;                                                                          \
+            ex->assume_x_zero = xz;                                                                             \
+            assumed = FALSE;                                                                                    \
+            if (wrong) {                                                                                        \
+                HIPGUARD(hipStreamSynchronize(s));                                                              \
+                return TRUE;                                                                                    \
+            }                                                                                                   \
+        }                                                                                                       \
+        if (rnrm_init == 0.0) { /* x already solves the system (krylov.c:130 would normalise by zero) */      \
+            HIPGUARD(hipStreamSynchronize(s));                                                                  \
+            ex->stats.converged = TRUE;                                                                         \
+            return FALSE;                                                                                       \
+        }                                                                                                       \
+    } while (0)
+#define FIRST_READ_SYNC()                                                                                       \
+    do {                                                                                                        \
+        HIPGUARD(hipMemcpyAsync(ex->h_stat, ex->nrm_base, 5 * sizeof(f64), D2H, s));                            \
+        HIPGUARD(hipStreamSynchronize(s));                                                                      \
+        FIRST_RESOLVE();                                                                                        \
+    } while (0)
+    b32 pend = FALSE;            /* a convergence check has been enqueued and not been looked at yet */
+    b32 pend_first = FALSE;      /* ... and the first read of the solve travels with it */
+    index_type final_check = -1; /* beta index whose value decides convergence at the end-of-solve synchronisation */
     /* partitioned + fused norm + Jacobi tree on the (u,p) rows: update, Givens step and the next step's preconditioner
        application in one launch (csrc/k_blas.hip, cgs_update_pc_kernel) */
     const f64 *fj_d33 = NULL, *fj_d1 = NULL;
@@ -442,23 +526,27 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
             dfl_dsqrt_dev(ex->nrm, s);
         } else dfl_dnrm2(na, QCOL(0), ex->nrm, ex->work, s);
         HIPGUARD(hipMemcpyAsync(ex->beta, ex->nrm, sizeof(f64), D2D, s)); /* beta[0] = ||r|| */
-        HIPGUARD(hipMemcpyAsync(&rnrm, ex->nrm, sizeof(f64), D2H, s));
-        HIPGUARD(hipStreamSynchronize(s));
-        if (cycle == 0) {
-            rnrm_init = rnrm;
-            ex->stats.rnrm_init = rnrm_init;
-            if (ex->verbose)
-                fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", 0, rnrm_init, atol, 1.0, rtol);
-            if (rnrm_init == 0.0) { /* x already solves the system: the reference would normalise by zero here (krylov.c:130) */
-                ex->stats.converged = TRUE;
-                return;
-            }
+        if (cycle == 0 && lazy) {
+            /* ||r0|| reaches the host with the first convergence check (or right before x is first updated) */
         } else {
-            /* restart: the recomputed true residual decides */
-            if (ex->verbose)
-                fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e) [restart %d]\n", total, rnrm, atol,
-                        rnrm / (rnrm_init + DBL_EPSILON), rtol, cycle);
-            if (rnrm < atol || rnrm < (rnrm_init + 1e-16) * rtol) { converged = TRUE; break; }
+            HIPGUARD(hipMemcpyAsync(&rnrm, ex->nrm, sizeof(f64), D2H, s));
+            HIPGUARD(hipStreamSynchronize(s));
+            if (cycle == 0) {
+                rnrm_init = rnrm;
+                ex->stats.rnrm_init = rnrm_init;
+                if (ex->verbose)
+                    fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", 0, rnrm_init, atol, 1.0, rtol);
+                if (rnrm_init == 0.0) { /* x already solves the system: the reference would normalise by zero here (krylov.c:130) */
+                    ex->stats.converged = TRUE;
+                    return FALSE;
+                }
+            } else {
+                /* restart: the recomputed true residual decides */
+                if (ex->verbose)
+                    fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e) [restart %d]\n", total, rnrm, atol,
+                            rnrm / (rnrm_init + DBL_EPSILON), rtol, cycle);
+                if (rnrm < atol || rnrm < (rnrm_init + 1e-16) * rtol) { converged = TRUE; break; }
+            }
         }
 
         /* the normalisation of Q[:,k] is folded into the preconditioner application that consumes it;
@@ -520,23 +608,54 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
                                                                     ex->work, iter, H, ldh, ex->gv, ex->beta, res_hist, s));
             }
         arnoldi_step_done:
-            if ((total + 1) % ex->check_interval == 0) {
-                HIPGUARD(hipMemcpyAsync(&rnrm, ex->beta + iter + 1, sizeof(f64), D2H, s));
-                HIPGUARD(hipStreamSynchronize(s));
-                rnrm = fabs(rnrm);
-                if (ex->verbose) {
-                    fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", total + 1, rnrm, atol,
-                            rnrm / (rnrm_init + DBL_EPSILON), rtol);
-                    fflush(stdout);
+            if (pend) {
+                /* the check enqueued behind the PREVIOUS iteration: the device has the iteration just enqueued to work on
+                   while the host waits for the 8 (+ 40) bytes */
+                HIPGUARD(hipEventSynchronize(ex->ev_stat));
+                pend = FALSE;
+                if (pend_first) { pend_first = FALSE; FIRST_RESOLVE(); }
+                rnrm = fabs(ex->h_stat[8]);
+                if (rnrm < atol || rnrm < (rnrm_init + 1e-16) * rtol) {
+                    converged = TRUE; /* the iteration enqueued meanwhile is not counted */
+                    break;
                 }
-                if (rnrm < atol || rnrm < (rnrm_init + 1e-16) * rtol) converged = TRUE;
+            }
+            if ((total + 1) % ex->check_interval == 0) {
+                if (!lazy) {
+                    HIPGUARD(hipMemcpyAsync(&rnrm, ex->beta + iter + 1, sizeof(f64), D2H, s));
+                    HIPGUARD(hipStreamSynchronize(s));
+                    rnrm = fabs(rnrm);
+                    if (ex->verbose) {
+                        fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", total + 1, rnrm, atol,
+                                rnrm / (rnrm_init + DBL_EPSILON), rtol);
+                        fflush(stdout);
+                    }
+                    if (rnrm < atol || rnrm < (rnrm_init + 1e-16) * rtol) converged = TRUE;
+                } else if (iter + 1 >= m || total + 1 >= maxit) {
+                    final_check = iter + 1; /* the loop ends here anyway: decided at the end-of-solve synchronisation */
+                } else {
+                    if (!first_read_done) {
+                        HIPGUARD(hipMemcpyAsync(ex->h_stat, ex->nrm_base, 5 * sizeof(f64), D2H, s));
+                        pend_first = TRUE;
+                    }
+                    HIPGUARD(hipMemcpyAsync(ex->h_stat + 8, ex->beta + iter + 1, sizeof(f64), D2H, s));
+                    HIPGUARD(hipEventRecord(ex->ev_stat, s));
+                    pend = TRUE;
+                }
             }
             iter++;
             total++;
         }
+        if (pend) { /* (cannot happen: a check on the last iteration is never left pending) */
+            HIPGUARD(hipEventSynchronize(ex->ev_stat));
+            pend = FALSE;
+            if (pend_first) { pend_first = FALSE; FIRST_RESOLVE(); }
+        }
 
+        if (!first_read_done) FIRST_READ_SYNC(); /* a solve shorter than its check interval: nothing has been read yet */
         if (iter) {
             /* 5.1 H y = beta   5.2 tmp = Q[:,0:iter] y   5.3 precondition   5.4 x += . */
+            if (final_check >= 0) HIPGUARD(hipMemcpyAsync(ex->h_stat + 9, ex->beta + final_check, sizeof(f64), D2H, s)); /* before trsv overwrites beta */
             dfl_gmres_trsv(iter, H, ldh, ex->beta, s);
             /* column `iter` may still be un-normalised, but it is not used; columns < iter are normalised */
             if (Zb) { /* FGMRES: x += Z y */
@@ -552,19 +671,25 @@ static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     index_type nh = total < 512 ? total : 512;
     if (nh) HIPGUARD(hipMemcpyAsync(ex->stats.res_hist, ex->res_hist, sizeof(f64) * (size_t)nh, D2H, s));
     ex->stats.fused_norm_cancelled = FALSE;
+    int flag = 0;
     if (dist && ex->fused_norm) {
-        int flag = 0;
         HIPGUARD(hipMemcpyAsync(&flag, ex->d_flag, sizeof flag, D2H, s));
-        HIPGUARD(hipStreamSynchronize(s));
-        ex->stats.fused_norm_cancelled = flag != 0;
         HIPGUARD(hipMemsetAsync(ex->d_flag, 0, sizeof(int), s));
     }
-    HIPGUARD(hipStreamSynchronize(s));
+    HIPGUARD(hipStreamSynchronize(s)); /* the one synchronisation at the end: history, cancellation flag, a last check */
+    ex->stats.fused_norm_cancelled = flag != 0;
+    if (final_check >= 0 && !converged) {
+        rnrm = fabs(ex->h_stat[9]);
+        if (rnrm < atol || rnrm < (rnrm_init + 1e-16) * rtol) converged = TRUE;
+    }
     ex->stats.iterations = total;
     ex->stats.converged = converged;
+    return FALSE;
 #undef QCOL
 #undef HCOL
 #undef ZCOL
+#undef FIRST_READ_SYNC
+#undef FIRST_RESOLVE
 }
 
 /* Preconditioned conjugate gradients.  The reference's CGSolvePrivate is an empty stub
@@ -653,6 +778,10 @@ void KrylovDestroy(Krylov* ksp) {
     if (!ksp) return;
     PCDestroy((PC*)ksp->pc);
     ws_free(kext(ksp));
+    if (kext(ksp)->h_stat) {
+        HIPGUARD(hipHostFree(kext(ksp)->h_stat));
+        HIPGUARD(hipEventDestroy(kext(ksp)->ev_stat));
+    }
     CdamFreeHost(ksp->ext, SIZE_OF(KrylovExt));
     CdamFreeHost(ksp, SIZE_OF(Krylov));
 }

@@ -26,6 +26,12 @@ typedef struct KrylovExt {
     b32 ws_fresh;  /* the basis was (re)allocated and its placement has not been calibrated yet */
     f64 *Q, *Z, *H, *tmp, *gv, *beta, *res_hist, *nrm, *work;
     int64_t work_len;
+    /* host reads of a solve without idling the GPU (GMRESSolvePrivate): probes + ||r0|| travel with the first convergence
+       check, the check itself is read one iteration late */
+    f64* nrm_base;      /* allocation behind nrm: [tail probe, x probe, -, -, nrm[0], ...] */
+    f64* h_stat;        /* pinned host staging [16] */
+    hipEvent_t ev_stat;
+    b32 assume_valid, assume_tail_zero, assume_x_zero; /* what the previous solve of this solver found (verified per solve) */
     b32 no_calibration; /* inner / coarse solvers of PC_TWOLEVEL: never time basis placements (DflKrylovMarkInner) */
 } KrylovExt;
 
