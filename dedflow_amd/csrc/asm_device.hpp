@@ -79,6 +79,54 @@ __device__ __forceinline__ void tet_geometry(const double* x, double* invJ, doub
     shg[2] = -shg[5] - shg[8] - shg[11];
 }
 
+// 1 / sqrt(x) and 1 / x for the per-tet part of the slot-owner Jacobian kernel (x > 0 and finite there: sums of squares plus
+// 4 / dt^2, a determinant of a valid tet, a trace of a positive definite metric): the hardware estimate (v_rsq_f64 /
+// v_rcp_f64, about 2^-23 relative) refined by Newton steps -- ONE for the reciprocal square root (relative error
+// (3/2) e^2 ~ 2e-14, the stabilisation parameters enter the blocks linearly) and TWO for the reciprocal (full precision:
+// every shape gradient carries it) -- instead of the library's IEEE expansions with their special-case selects
+// (~11 and ~13 instructions each; ten of them per tet were a sixth of phase 1).  Deterministic, so the kernel stays
+// bitwise reproducible; the deviation from the oracle is bounded by the 1e-10 parity tests.
+__device__ __forceinline__ double rsqrt_nr1(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);  // 1 - x y^2
+    return fma(0.5 * y, e, y);
+}
+__device__ __forceinline__ double rcp_nr2(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+
+template <bool FAST = false>
+__device__ __forceinline__ void tet_geometry_t(const double* x, double* invJ, double& detJ, double* shg) {
+    const double j00 = x[3] - x[0], j10 = x[4] - x[1], j20 = x[5] - x[2];   // column 0 = x1 - x0
+    const double j01 = x[6] - x[0], j11 = x[7] - x[1], j21 = x[8] - x[2];   // column 1 = x2 - x0
+    const double j02 = x[9] - x[0], j12 = x[10] - x[1], j22 = x[11] - x[2]; // column 2 = x3 - x0
+    const double c00 = j11 * j22 - j12 * j21;
+    const double c01 = j12 * j20 - j10 * j22;
+    const double c02 = j10 * j21 - j11 * j20;
+    const double det = j00 * c00 + j01 * c01 + j02 * c02;
+    const double id = FAST ? rcp_nr2(det) : 1.0 / det;
+    detJ = fabs(det);
+    invJ[0 + 3 * 0] = c00 * id;
+    invJ[0 + 3 * 1] = (j02 * j21 - j01 * j22) * id;
+    invJ[0 + 3 * 2] = (j01 * j12 - j02 * j11) * id;
+    invJ[1 + 3 * 0] = c01 * id;
+    invJ[1 + 3 * 1] = (j00 * j22 - j02 * j20) * id;
+    invJ[1 + 3 * 2] = (j02 * j10 - j00 * j12) * id;
+    invJ[2 + 3 * 0] = c02 * id;
+    invJ[2 + 3 * 1] = (j01 * j20 - j00 * j21) * id;
+    invJ[2 + 3 * 2] = (j00 * j11 - j01 * j10) * id;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) shg[i * 3 + j + 3] = invJ[i + j * 3];
+    shg[0] = -shg[3] - shg[6] - shg[9];
+    shg[1] = -shg[4] - shg[7] - shg[10];
+    shg[2] = -shg[5] - shg[8] - shg[11];
+}
+
 __device__ __forceinline__ void tet_metric(const double* shg, double* G) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)

@@ -19,7 +19,12 @@
 namespace {
 
 constexpr int SBLK = DFL_SLOT_BLOCK;
-constexpr int SP_RS = 36;  // doubles per LDS tet record: shg[12] conv[a][q] (16) tauM[4] | cT, w | sum tauM, cK (asm_device.hpp)
+constexpr int SP_RV = 36;  // doubles of an LDS tet record in use: shg[12] conv[a][q] (16) tauM[4] | cT, w | sum tauM, cK (asm_device.hpp)
+// Record STRIDE: the lanes of a wave read the records of unrelated tets with 16-byte accesses.  At 36 doubles = 72 dwords the
+// start banks of two records differ by a multiple of 8: eight distinct starts, 51 % of the LDS cycles were bank conflicts
+// (profiles/r02e_pmc_lhs.txt).  38 doubles = 76 dwords = 4 x 19: the 16 possible starts of a 16-byte access are all
+// reached (start bank = 12 t mod 64), and 128 tets still fit four workgroups per CU (38.9 KB each).
+constexpr int SP_RS = 38;
 
 typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
 
@@ -60,12 +65,12 @@ __device__ __forceinline__ void slot_tet_record(const double2* r, double* rec) {
         u[b * 3] = r[3 * b + 1].y; u[b * 3 + 1] = r[3 * b + 2].x; u[b * 3 + 2] = r[3 * b + 2].y;
     }
     double invJ[9], shg[12], G[9], detJ;
-    tet_geometry(x, invJ, detJ, shg);
+    tet_geometry_t<true>(x, invJ, detJ, shg);
     tet_metric(shg, G);
     double gg = 0.0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) gg += G[k] * G[k];
-    const double itr = 1.0 / (G[0] + G[4] + G[8]);
+    const double itr = rcp_nr2(G[0] + G[4] + G[8]);
 #pragma unroll
     for (int k = 0; k < 12; ++k) rec[k] = shg[k];
     double su[3];
@@ -86,9 +91,9 @@ __device__ __forceinline__ void slot_tet_record(const double2* r, double* rec) {
         }
         // |J^-1 u|^2 (rows of J^-1 = shape gradients of nodes 1..3) and the stabilisation parameters (:587-603)
         const double y = cv[1] * cv[1] + cv[2] * cv[2] + cv[3] * cv[3] + (3.0 * knu * knu) * gg;
-        t0v[q] = rsqrt(4.0 / (kDT * kDT) + y) * (1.0 / kRHO);
+        t0v[q] = rsqrt_nr1(4.0 / (kDT * kDT) + y) * (1.0 / kRHO);
         rec[28 + q] = t0v[q];
-        s_t1 += y * rsqrt(y) * itr;  // tauC enters the block only through its sum over the quadrature points
+        s_t1 += y * rsqrt_nr1(y) * itr;  // tauC enters the block only through its sum over the quadrature points
     }
     // the four numbers every block of the tet starts from (lhs_block_accumulate), formed once here instead of 16 times there
     const double fact2 = kDT * kALPHAF * kGAMMA;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 4) void tet_lhs_slot_kernel(I P, 
                                                            const I* __restrict__ slot_nz, const unsigned* __restrict__ ldesc,
                                                            const T* __restrict__ nodep, T* __restrict__ val, T beta, int max_tets, int dbg_in) {
     static_assert(SBLK == 256, "trip bytes: four waves x two passes");
-    const int dbg = PROBE ? dbg_in : 0;
+    const int dbg = PROBE ? (dbg_in & ~(1 << 30)) : 0;
     extern __shared__ __attribute__((aligned(16))) double s_tet[];
     // XCD-aware order: workgroup w runs on XCD w % 8; every XCD gets one contiguous range of the spatially ordered
     // patches (neighbouring patches share tets and node records -> one L2), dealt round-robin to its workgroups
@@ -119,7 +124,15 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 4) void tet_lhs_slot_kernel(I P, 
     const int pend = min((int)P, pbeg + per);
     int p = pbeg + (blockIdx.x >> 3);
     if (p >= pend) return;
-    const int t = threadIdx.x;
+    // Role rotation (developer A/B, DFL_SLOT_ROTATION=1; off by default).  The four waves of a workgroup carry different loads:
+    // logical wave 0 runs phase 1 (90 tets fill waves 0 and 1), the positions with the most contributions and the split-slot
+    // reduction -- about 770 VALU instructions per patch against 316 for logical wave 3 -- and the counters say VALU busy 65 % =
+    // (770 + 700 + 316 + 316) / (4 x 770), as if wave i of every workgroup shared SIMD i with its like.  Rotating the roles
+    // between the workgroups of a CU (logical thread = physical thread + 64 rot) should then level the SIMDs; measured: 2.32 ms
+    // against 2.17 ms without (same box, gpurun_out/r3e), like round 2's alternation of the phase-1 half.  The hardware does not
+    // pin wave i to SIMD i; what bounds a patch is its heaviest wave's own dependent chain at a quarter share of a SIMD.
+    const int rot = (dbg_in & (1 << 30)) ? (int)((blockIdx.x >> 8) & 3u) : 0;
+    const int t = (int)((threadIdx.x + 64u * (unsigned)rot) & (unsigned)(SBLK - 1));
     const int lane = t & 63, pr = t >> 1;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int4 zero4 = make_int4(0, 0, 0, 0);
@@ -237,15 +250,24 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 4) void tet_lhs_slot_kernel(I P, 
                     e[k].x = (hi1 ? acc[4 * k + 2] : acc[4 * k]) + dpp_quad<0xB1>(hi1 ? acc[4 * k] : acc[4 * k + 2]);
                     e[k].y = (hi1 ? acc[4 * k + 3] : acc[4 * k + 1]) + dpp_quad<0xB1>(hi1 ? acc[4 * k + 1] : acc[4 * k + 3]);
                 }
-                if (nzr & 0xC0000000) {
-                    // split slot (host/slotpatch.c): its four parts sit in four adjacent pairs (half a 16-lane DPP row, aligned);
-                    // lane j of the first pair collects lane j of the others: (p0 + p1) + (p2 + p3), two row shifts
+                // split slot (host/slotpatch.c): its four parts sit in four adjacent pairs (half a 16-lane DPP row, aligned);
+                // lane j of the first pair collects lane j of the others: (p0 + p1) + (p2 + p3), two row shifts.  The branch
+                // is on a WAVE-uniform condition: the split positions are ranked first, so in a 7-node patch they all sit in
+                // wave 0 and the other three waves skip the 32 DPP moves + 16 adds (left to the compiler the per-lane `if`
+                // became predicated code that every position paid for: 65 of the 116 instructions of this epilogue)
+                if (__builtin_amdgcn_ballot_w64((nzr & 0xC0000000) != 0) != 0ull) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { e[k].x += dpp_quad<0x102>(e[k].x); e[k].y += dpp_quad<0x102>(e[k].y); }
+                    for (int k = 0; k < 4; ++k) {
+                        const double sx = dpp_quad<0x102>(e[k].x), sy = dpp_quad<0x102>(e[k].y);
+                        if (nzr & 0xC0000000) { e[k].x += sx; e[k].y += sy; }
+                    }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { e[k].x += dpp_quad<0x104>(e[k].x); e[k].y += dpp_quad<0x104>(e[k].y); }
-                    if (nzr < 0) continue;  // only the first pair stores
+                    for (int k = 0; k < 4; ++k) {
+                        const double sx = dpp_quad<0x104>(e[k].x), sy = dpp_quad<0x104>(e[k].y);
+                        if (nzr & 0xC0000000) { e[k].x += sx; e[k].y += sy; }
+                    }
                 }
+                if (nzr < 0) continue;  // followers of a split slot (and positions past the patch): only the first pair stores
                 if ((PROBE & 8) && (dbg & 8)) {
                     if (e[0].x == 1.2345e300) val[nz] = e[0].x + e[0].y + e[1].x + e[1].y + e[2].x + e[2].y + e[3].x + e[3].y;
                     continue;
@@ -710,7 +732,10 @@ void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const I* ptet_ien, 
     if (grid > need) grid = need;
     const int4* h4 = reinterpret_cast<const int4*>(hdr);
     const int4* pi4 = reinterpret_cast<const int4*>(ptet_ien);
-#define SLOT_LAUNCH(B0, PR, EA) tet_lhs_slot_kernel<B0, PR, EA><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, ldesc, nodep, val, beta, max_tets, probe)
+    static int rot_on = -1;  // DFL_SLOT_ROTATION=1: co-resident workgroups rotate the wave roles (A/B; slower, see the kernel)
+    if (rot_on < 0) rot_on = getenv("DFL_SLOT_ROTATION") ? 1 : 0;
+    const int kflags = probe | (rot_on ? (1 << 30) : 0);
+#define SLOT_LAUNCH(B0, PR, EA) tet_lhs_slot_kernel<B0, PR, EA><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, ldesc, nodep, val, beta, max_tets, kflags)
     if (probe) {
         if (early) SLOT_LAUNCH(true, 15, true); else SLOT_LAUNCH(true, 15, false);
     } else if (beta == 0.0) {
