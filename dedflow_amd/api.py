@@ -294,7 +294,7 @@ def _declare(L):
     f("PCSetup", None, [vp]); f("PCApply", None, [vp, vp, vp]); f("PCDestroy", None, [vp])
     f("PCCreateJacobi", vp, [C.POINTER(Matrix), i32, vp]); f("PCCreateNone", vp, [C.POINTER(Matrix), i32])
     f("PCCreateDILU", vp, [C.POINTER(Matrix)]); f("PCDILUGetColors", i32, [vp, vp]); f("PCDILUGetInverseBlocks", vp, [vp])
-    f("KrylovSetPCType", None, [vp, C.c_int]); f("KrylovGetPC", vp, [vp]); f("KrylovSetFusedNorm", None, [vp, C.c_int]); f("KrylovSetRestart", None, [vp, i32])
+    f("KrylovSetPCType", None, [vp, C.c_int]); f("KrylovGetPC", vp, [vp]); f("KrylovSetFusedNorm", None, [vp, C.c_int]); f("KrylovSetPipelined", None, [vp, C.c_int]); f("KrylovSetRestart", None, [vp, i32])
     f("KrylovSetFlexible", None, [vp, i32]); f("KrylovSetMesh", None, [vp, C.POINTER(Mesh3D)]); f("KrylovSetAggregateSize", None, [vp, i32])
     f("PCTwoLevelInfo", None, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_int64)]); f("PCTwoLevelAggregates", vp, [vp])
     f("PCTwoLevelCoarseMatrix", C.POINTER(Matrix), [vp]); f("PCTwoLevelSetInner", None, [vp, i32, f64])

@@ -100,6 +100,13 @@ def run(args, rank, world, local_rank):
         local_rank = int(os.environ["DFL_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world == 1:   # DFL_FORCE_DIST=1 rehearsal without a launcher: loopback rendezvous on a free port
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     staged = backend != "nccl"
 
@@ -157,22 +164,63 @@ def run(args, rank, world, local_rank):
         step()
     torch.cuda.synchronize()
 
-    # rank 0's local SpMV against the HBM roofline (owned rows only; same per-unit bytes as the 1-GPU line)
+    # rank 0's local SpMV against the HBM roofline (same per-unit bytes as the 1-GPU line).  A partitioned matvec is the
+    # interior rows on the library stream (while the halo is in flight) plus the boundary rows; with the C-level RCCL
+    # communicator the boundary rows run on the halo stream beside the interior launch and are not inside the library
+    # stream's event pairs: then the figure is the INTERIOR launch alone against the bytes of the interior rows
     tot, mn = C.c_double(0), C.c_double(0)
     n_spmv = L.DflProfileCollect(0, C.byref(tot), C.byref(mn))
     L.DflProfileEnable(0)
     rp, _ = P.pattern()
-    spmv_bytes = 132.0 * float(rp[no]) + 4.0 * (no + 1) + 64.0 * no
-    # a partitioned matvec is TWO launches (interior rows while the halo is in flight, then the boundary rows) whenever the
-    # rank has interior rows: the roofline figure is per matvec (both launches), not per launch
     split = 0 < lm.n_interior <= no
-    n_matvec = n_spmv // 2 if split else n_spmv
+    side_rows = split and type(comm).__name__ == "RcclSolverComm" and os.environ.get("DFL_NO_SIDE_BOUNDARY_ROWS") is None
+    nrow = lm.n_interior if side_rows else no
+    spmv_bytes = 132.0 * float(rp[nrow]) + 4.0 * (nrow + 1) + 64.0 * nrow
+    n_matvec = n_spmv if (side_rows or not split) else n_spmv // 2
     roofline = None
     if n_matvec and tot.value > 0:
         gbps = spmv_bytes * n_matvec / (tot.value * 1e-3) / 1e9
-        roofline = {"kernel": "spmv (rank 0, owned rows%s)" % (", interior + boundary launch" if split else ""), "bound": "hbm",
+        what = ("interior rows (boundary rows overlap them on the halo stream)" if side_rows else
+                "owned rows, interior + boundary launch" if split else "owned rows")
+        roofline = {"kernel": "spmv (rank 0, %s)" % what, "bound": "hbm",
                     "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None,
                     "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": tot.value / n_matvec}
+
+    # ---- time to the reference's tolerance (rtol 1e-4, main.c:406) on the partitioned system: PC_TWOLEVEL (aggregates per
+    # rank, replicated Galerkin coarse problem, rank-local DILU smoothing; FGMRES) -- outside the timed steps; every rank takes
+    # part (the preconditioner's setup and application are collective)
+    to_rtol = None
+    n_extra_solves = 0
+    n_steps_counted = args.steps + args.warmup + min(args.steps, 3)
+    coll_allreduce, coll_halo = comm.n_allreduce // n_steps_counted, comm.n_halo // n_steps_counted   # before the extra leg
+    if getattr(args, "solve_to_rtol", 1):
+        ksp_i = C.cast(P.ksp, C.POINTER(C.c_int32))
+        ksp_f = C.cast(P.ksp, C.POINTER(C.c_double))
+        ksp_i[0] = 100
+        ksp_f[1], ksp_f[2] = 1e-12, 1e-4
+        L.KrylovSetFusedNorm(P.ksp, 0)
+        L.KrylovSetPCType(P.ksp, api.PC_TWOLEVEL)
+        res = []
+        for rep in range(2):              # the first solve builds the aggregates and the replicated coarse matrix
+            x_t.zero_()
+            torch.cuda.synchronize(); dist.barrier(); tw = time.perf_counter()
+            it3, r03, hist3, conv3 = P.solve(_Ptr(x_p), _Ptr(F_p))
+            torch.cuda.synchronize(); dist.barrier(); res.append(time.perf_counter() - tw)
+            n_extra_solves += 1
+        pc = L.KrylovGetPC(P.ksp)
+        is_tl = bool(pc) and C.cast(pc, C.POINTER(C.c_int))[0] == api.PC_TWOLEVEL
+        nagg, cnnz, inner = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+        if is_tl:
+            L.PCTwoLevelInfo(pc, C.byref(nagg), C.byref(cnnz), C.byref(inner))
+        to_rtol = {"pc": "PC_TWOLEVEL on the partitioned matrix (rank-local block-DILU smoother + replicated aggregation coarse level, FGMRES)"
+                         if is_tl else "PC_ILU0 fall-back (PC_TWOLEVEL unavailable)",
+                   "rtol": 1e-4, "iterations": it3, "converged": bool(conv3), "ms": 1e3 * res[-1],
+                   "first_solve_incl_hierarchy_build_ms": 1e3 * res[0], "coarse_nodes": nagg.value, "coarse_nnz": cnnz.value,
+                   "relative_residual": float(hist3[-1] / r03) if len(hist3) else None, "dofs_per_s": 4.0 * Ng / res[-1],
+                   "collectives_per_application": "1 halo exchange + 1 all-reduce of 4 x coarse_nodes doubles (+ the outer solver's own)"}
+        L.KrylovSetPCType(P.ksp, api.PC_DECOMPOSITION)
+        ksp_i[0] = its
+        ksp_f[1], ksp_f[2] = 0.0, 0.0
 
     stats = torch.tensor([float(P.T), float(no), float(plan.bytes_per_exchange), float(P.num_color)], dtype=torch.float64,
                          device="cpu" if staged else device)
@@ -194,9 +242,8 @@ def run(args, rank, world, local_rank):
                          "halo_send_bytes": [r[2] for r in per_rank], "colors": [r[3] for r in per_rank]},
             "redundant_assembly_fraction": sum(r[0] for r in per_rank) / Tg - 1.0,
             "communicator": type(comm).__name__, "fused_norm_allreduce": bool(fused),
-            "collectives_per_step": {"allreduce": comm.n_allreduce // (args.steps + args.warmup + min(args.steps, 3)),
-                                     "halo_exchange": comm.n_halo // (args.steps + args.warmup + min(args.steps, 3))},
-            "roofline": roofline, "cpu_baseline": None, "setup_s": t_setup,
+            "collectives_per_step": {"allreduce": coll_allreduce, "halo_exchange": coll_halo},
+            "roofline": roofline, "cpu_baseline": None, "setup_s": t_setup, "solve_to_rtol": to_rtol,
             "gmres_residual_drop": float(hist[-1] / r0) if len(hist) else None,
         }
         print(json.dumps(out))

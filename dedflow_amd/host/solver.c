@@ -241,6 +241,7 @@ void KrylovSetPCType(Krylov* k, PCType type) {
 }
 PC* KrylovGetPC(const Krylov* k) { return (PC*)k->pc; }
 void KrylovSetFusedNorm(Krylov* k, b32 on) { kext(k)->fused_norm = on; }
+void KrylovSetPipelined(Krylov* k, b32 on) { kext(k)->pipelined = on; }
 void KrylovSetRestart(Krylov* k, index_type m) { kext(k)->restart = m; }
 void KrylovSetFlexible(Krylov* k, b32 on) {
     kext(k)->flexible = on;
@@ -378,6 +379,171 @@ static void zero_ghost_rows(const KrylovExt* ex, Matrix* A, f64* v, index_type n
         HIPGUARD(hipMemsetAsync(v + (size_t)sec * N + no, 0, (size_t)(N - no) * sizeof(f64), s));
 }
 
+/* p(1)-pipelined GMRES (KrylovSetPipelined; off by default; build-defined -- the reference has no multi-GPU path and its
+ * AMGX sketch, krylov.c:409-437, no pipelining).  After Ghysels, Ashby, Meerbergen, Vanroose (SIAM J. Sci. Comput. 35, 2013):
+ * with B = A M^-1 and the auxiliary basis z_{j+1} = B v_j kept next to V, the product the NEXT Arnoldi step needs follows
+ * from one applied to the UN-orthogonalised vector,
+ *     B v_{i+1} = ( B z_{i+1} - sum_j h_{j,i} z_{j+1} ) / h_{i+1,i},
+ * so the matvec u = B z_{i+1} (preconditioner, halo exchange, SpMV) runs WHILE the one reduction of the step -- the CGS
+ * coefficients <z_{i+1}, v_j> together with <z_{i+1}, z_{i+1}>; h_{i+1,i} from the Pythagorean identity as in the fused-norm
+ * option -- crosses the ranks: the all-reduce latency (the exposed 20-30 us per iteration of an 8-rank step) hides behind
+ * 80+ us of matvec.  The dots and the all-reduce go to a stream of their own when the communicator is stream-ordered (the
+ * C-level RCCL one: it exposes halo_stream); with host-side communicators (the torch.distributed callbacks of the gloo
+ * tests) everything stays on the library stream: same arithmetic, no overlap.
+ * Price: a second basis (memory x2), a third pass over a basis per step (+50 % CGS traffic), one wasted matvec at the end,
+ * and the numerics of the z-recurrence plus the Pythagorean norm (cancellation flagged in KrylovStats.fused_norm_cancelled):
+ * the residual history follows the reference's to ~1e-8 r0 over 40 steps on the test systems, not to 1e-10.  Fixed
+ * (non-flexible) preconditioners only, no restarts; convergence is tested every check interval with an eager read. */
+static void gmres_pipelined(Matrix* A, f64* x, f64* b, Krylov* ksp) {
+    KrylovExt* ex = kext(ksp);
+    PC* pc = (PC*)ksp->pc;
+    hipStream_t s = DflStream();
+    const index_type maxit = ksp->max_iter, m = maxit;
+    const f64 atol = ksp->atol, rtol = ksp->rtol;
+    const index_type n = MatrixNumRow(A);
+    const index_type ldh = CEIL_DIV(m + 1, 32) * 32;
+    const b32 dist = ex->has_comm;
+    ws_ensure(ex, n, m, ldh, maxit);
+    ex->ws_fresh = FALSE; /* no placement calibration for this form */
+    index_type na = n;
+    {
+        b32 tail_zero = FALSE, unused = FALSE;
+        const b32 up_system = MatrixFSBlockValues(A) && n == 6 * ((MatrixFS*)A->data)->spy1x1->num_row;
+        probe_operands(b, up_system ? 4 * (n / 6) : n, n, NULL, ex->work, &tail_zero, &unused);
+        if (up_system && tail_zero) na = 4 * (n / 6);
+    }
+    if (!ex->Zp || ex->zp_n != n || ex->zp_m != m) {
+        DflWsVecFreeAs(ex->Zp, ex->zp_pooled);
+        ex->zp_pooled = DflWsInPool();
+        ex->Zp = ws_vec_malloc((ptrdiff_t)n * (m + 2));
+        ex->zp_n = n;
+        ex->zp_m = m;
+    }
+    const b32 own_stream = dist && ex->comm.halo_stream && ex->comm.halo_stream(ex->comm.ctx) != NULL;
+    if (own_stream && !ex->red_stream) {
+        HIPGUARD(hipStreamCreateWithFlags(&ex->red_stream, hipStreamNonBlocking));
+        HIPGUARD(hipEventCreateWithFlags(&ex->ev_w, hipEventDisableTiming));
+        HIPGUARD(hipEventCreateWithFlags(&ex->ev_h, hipEventDisableTiming));
+    }
+    hipStream_t rs = own_stream ? ex->red_stream : s;
+    f64 *V = ex->Q, *Z = ex->Zp, *H = ex->H, *tmp = ex->tmp;
+#define VCOL(c) (V + (size_t)(c) * (size_t)na)
+#define ZPCOL(c) (Z + (size_t)(c) * (size_t)na)
+#define HCOL(c) (H + (size_t)(c) * (size_t)ldh)
+    const index_type n_interior = dist ? ex->comm.num_interior_node : 0;
+    const b32 split_rows = dist && n_interior > 0 && MatrixFSBlockValues(A) && n_interior <= MatrixFSOwnedRows(A);
+    ex->stats.converged = FALSE;
+    ex->stats.iterations = 0;
+    HIPGUARD(hipMemsetAsync(H, 0, (size_t)ldh * m * sizeof(f64), s));
+    HIPGUARD(hipMemsetAsync(ex->beta, 0, ((size_t)m + 1) * sizeof(f64), s));
+    HIPGUARD(hipMemsetAsync(ex->gv, 0, 2 * (size_t)m * sizeof(f64), s));
+    /* u = A M^-1 src  (owned rows; the halo exchange overlaps the interior rows where the communicator can) */
+#define APPLY_B(src, dst)                                                                                        \
+    do {                                                                                                         \
+        DflPcApplyFused(pc, na, (src), NULL, tmp);                                                               \
+        if (dist && split_rows) {                                                                                \
+            if (ex->comm.halo_begin) ex->comm.halo_begin(ex->comm.ctx, tmp);                                     \
+            else ex->comm.halo_exchange(ex->comm.ctx, tmp);                                                      \
+            MatrixFSMatVecRange(A, tmp, (dst), 0, n_interior);                                                   \
+            hipStream_t side_ = (ex->comm.halo_begin && ex->comm.halo_stream) ? ex->comm.halo_stream(ex->comm.ctx) : NULL; \
+            if (side_) {                                                                                         \
+                DflSetStream(side_);                                                                             \
+                MatrixFSMatVecRange(A, tmp, (dst), n_interior, MatrixFSOwnedRows(A));                            \
+                DflSetStream(s);                                                                                 \
+                ex->comm.halo_end(ex->comm.ctx, tmp);                                                            \
+            } else {                                                                                             \
+                if (ex->comm.halo_begin) ex->comm.halo_end(ex->comm.ctx, tmp);                                   \
+                MatrixFSMatVecRange(A, tmp, (dst), n_interior, MatrixFSOwnedRows(A));                            \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            if (dist) ex->comm.halo_exchange(ex->comm.ctx, tmp);                                                 \
+            MatrixMatVec(A, tmp, (dst));                                                                         \
+        }                                                                                                        \
+    } while (0)
+
+    /* r0 = b - A x, v_0 = r0 / ||r0||, z_1 = B v_0 */
+    f64 rnrm_init = 0.0, rnrm = 0.0;
+    dfl_dcopy(na, b, VCOL(0), s);
+    if (dist) ex->comm.halo_exchange(ex->comm.ctx, x);
+    MatrixAMVPBY(A, -1.0, x, 1.0, VCOL(0));
+    if (dist) {
+        zero_ghost_rows(ex, A, VCOL(0), na);
+        dfl_ddot(na, VCOL(0), VCOL(0), ex->nrm, ex->work, s);
+        ex->comm.allreduce_sum(ex->comm.ctx, ex->nrm, 1);
+        dfl_dsqrt_dev(ex->nrm, s);
+    } else dfl_dnrm2(na, VCOL(0), ex->nrm, ex->work, s);
+    HIPGUARD(hipMemcpyAsync(ex->beta, ex->nrm, sizeof(f64), D2D, s));
+    HIPGUARD(hipMemcpyAsync(&rnrm_init, ex->nrm, sizeof(f64), D2H, s));
+    HIPGUARD(hipStreamSynchronize(s));
+    ex->stats.rnrm_init = rnrm_init;
+    if (ex->verbose) fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", 0, rnrm_init, atol, 1.0, rtol);
+    if (rnrm_init == 0.0) { ex->stats.converged = TRUE; return; }
+    dfl_dscal_inv_dev(na, ex->nrm, VCOL(0), s);
+    APPLY_B(VCOL(0), ZPCOL(1));
+
+    b32 converged = FALSE;
+    index_type iter = 0;
+    while (!converged && iter < m) {
+        const b32 last = iter + 1 >= m;
+        /* w = z_{iter+1}, kept in column iter+1 of V as in the reference's loop: the dots then give <w, w> with the h_j */
+        dfl_dcopy(na, ZPCOL(iter + 1), VCOL(iter + 1), s);
+        if (own_stream) {
+            HIPGUARD(hipEventRecord(ex->ev_w, s));
+            HIPGUARD(hipStreamWaitEvent(rs, ex->ev_w, 0));
+        }
+        /* the reduction of this step, on its own stream where the communicator allows */
+        dfl_cgs_dots(na, iter + 2, V, na, VCOL(iter + 1), HCOL(iter), ex->work, rs);
+        if (dist) {
+            if (own_stream) DflSetStream(rs);
+            ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 2);
+            if (own_stream) DflSetStream(s);
+        }
+        if (own_stream) HIPGUARD(hipEventRecord(ex->ev_h, rs));
+        /* ... and the matvec of the NEXT step meanwhile: u = B z_{iter+1} (not needed after the last column) */
+        if (!last) APPLY_B(ZPCOL(iter + 1), ZPCOL(iter + 2)); /* (ghost rows of Z stay zero: nothing ever writes them) */
+        if (own_stream) HIPGUARD(hipStreamWaitEvent(s, ex->ev_h, 0));
+        /* v_{iter+1} = w - V h,  z_{iter+2} = u - Z h  (raw column), then the norm from w.w - sum h^2 + the Givens step */
+        DFL_TIMED(DFL_TAG_CGS_UPDATE, dfl_cgs_update(na, iter + 1, V, na, HCOL(iter), VCOL(iter + 1), NULL, 0, ex->work, s));
+        if (!last) DFL_TIMED(DFL_TAG_CGS_UPDATE, dfl_cgs_update(na, iter + 1, ZPCOL(1), na, HCOL(iter), ZPCOL(iter + 2), NULL, 0, ex->work, s));
+        dfl_gmres_givens_pythagoras(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, ex->res_hist, ex->d_flag, s);
+        dfl_dscal_inv_dev(na, ex->nrm + iter + 1, VCOL(iter + 1), s);
+        if (!last) dfl_dscal_inv_dev(na, ex->nrm + iter + 1, ZPCOL(iter + 2), s);
+        if ((iter + 1) % ex->check_interval == 0) {
+            HIPGUARD(hipMemcpyAsync(&rnrm, ex->beta + iter + 1, sizeof(f64), D2H, s));
+            HIPGUARD(hipStreamSynchronize(s));
+            rnrm = fabs(rnrm);
+            if (ex->verbose) {
+                fprintf(stdout, "%3d) abs = %6.4e (tol = %6.4e) rel = %6.4e (tol = %6.4e)\n", iter + 1, rnrm, atol,
+                        rnrm / (rnrm_init + DBL_EPSILON), rtol);
+                fflush(stdout);
+            }
+            if (rnrm < atol || rnrm < (rnrm_init + 1e-16) * rtol) converged = TRUE;
+        }
+        iter++;
+    }
+    if (iter) { /* x += M^-1 V y */
+        dfl_gmres_trsv(iter, H, ldh, ex->beta, s);
+        dfl_gemv_n(na, iter, V, na, ex->beta, tmp, s);
+        DflPcApplyFused(pc, na, tmp, NULL, tmp + n);
+        dfl_daxpy(na, 1.0, tmp + n, x, s);
+    }
+    index_type nh = iter < 512 ? iter : 512;
+    if (nh) HIPGUARD(hipMemcpyAsync(ex->stats.res_hist, ex->res_hist, sizeof(f64) * (size_t)nh, D2H, s));
+    int flag = 0;
+    HIPGUARD(hipMemcpyAsync(&flag, ex->d_flag, sizeof flag, D2H, s));
+    HIPGUARD(hipMemsetAsync(ex->d_flag, 0, sizeof(int), s));
+    HIPGUARD(hipStreamSynchronize(s));
+    if (own_stream) HIPGUARD(hipStreamSynchronize(rs));
+    ex->stats.fused_norm_cancelled = flag != 0;
+    ex->stats.iterations = iter;
+    ex->stats.converged = converged;
+#undef APPLY_B
+#undef VCOL
+#undef ZPCOL
+#undef HCOL
+}
+
+
 /* Host reads without idling the GPU ("lazy" mode: quiet solver, no restarts).  The reference synchronises two to three times
  * per iteration; round 2 was down to: operand probe, ||r0||, one read per convergence check, two at the end -- each of them a
  * round trip during which the device sits idle (40-120 us; 0.38 ms of a rank's 8 ms step at 8 ranks).  Now:
@@ -395,6 +561,14 @@ static void zero_ghost_rows(const KrylovExt* ex, Matrix* A, f64* v, index_type n
 static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe);
 static void GMRESSolvePrivate(Matrix* A, f64* x, f64* b, void* ctx) {
     Krylov* ksp = (Krylov*)ctx;
+    {
+        KrylovExt* ex = kext(ksp);
+        const b32 restarted = ex->restart > 0 && ex->restart < ksp->max_iter;
+        if (ex->pipelined && !ex->flexible && !restarted && ksp->max_iter + 2 <= 1024) {
+            gmres_pipelined(A, x, b, ksp);
+            return;
+        }
+    }
     if (gmres_run(A, x, b, ksp, FALSE)) {
         const b32 again = gmres_run(A, x, b, ksp, TRUE);
         ASSERT(!again);
@@ -781,6 +955,13 @@ void KrylovDestroy(Krylov* ksp) {
     if (kext(ksp)->h_stat) {
         HIPGUARD(hipHostFree(kext(ksp)->h_stat));
         HIPGUARD(hipEventDestroy(kext(ksp)->ev_stat));
+    }
+    DflWsVecFreeAs(kext(ksp)->Zp, kext(ksp)->zp_pooled);
+    if (kext(ksp)->red_stream) {
+        HIPGUARD(hipStreamSynchronize(kext(ksp)->red_stream));
+        HIPGUARD(hipEventDestroy(kext(ksp)->ev_w));
+        HIPGUARD(hipEventDestroy(kext(ksp)->ev_h));
+        HIPGUARD(hipStreamDestroy(kext(ksp)->red_stream));
     }
     CdamFreeHost(ksp->ext, SIZE_OF(KrylovExt));
     CdamFreeHost(ksp, SIZE_OF(Krylov));

@@ -32,6 +32,13 @@ typedef struct KrylovExt {
     f64* h_stat;        /* pinned host staging [16] */
     hipEvent_t ev_stat;
     b32 assume_valid, assume_tail_zero, assume_x_zero; /* what the previous solve of this solver found (verified per solve) */
+    /* p(1)-pipelined GMRES (KrylovSetPipelined): auxiliary basis z_{j+1} = A M^-1 v_j, the reduction's own stream */
+    b32 pipelined;
+    f64* Zp;
+    index_type zp_n, zp_m;
+    int zp_pooled;
+    hipStream_t red_stream;
+    hipEvent_t ev_w, ev_h;
     b32 no_calibration; /* inner / coarse solvers of PC_TWOLEVEL: never time basis placements (DflKrylovMarkInner) */
 } KrylovExt;
 

@@ -440,6 +440,13 @@ PC* KrylovGetPC(const Krylov* krylov);
  * step needs ONE all-reduce (h and w.w together) instead of two; rounding differs from the explicit norm and heavy
  * cancellation raises KrylovStats.fused_norm_cancelled */
 void KrylovSetFusedNorm(Krylov* krylov, b32 on);
+/* p(1)-pipelined GMRES (host/solver.c, gmres_pipelined; build-defined, off by default): ONE reduction per Arnoldi step -- the CGS
+ * coefficients and w.w together, the norm from the Pythagorean identity -- overlapped with the matvec of the NEXT step through
+ * the auxiliary basis z_{j+1} = A M^-1 v_j (Ghysels et al. 2013).  Hides the all-reduce latency of partitioned runs behind the
+ * matvec (own stream with the RCCL communicator); costs a second basis, a third basis pass per step and some accuracy of the
+ * residual history (~1e-8 r0 instead of 1e-10; heavy cancellation raises KrylovStats.fused_norm_cancelled).  Ignored with
+ * FGMRES / PC_TWOLEVEL and with restarts. */
+void KrylovSetPipelined(Krylov* krylov, b32 on);
 /* GMRES(m): restart after m basis columns (x updated, true residual recomputed); m <= 0 or m >= max_iter (default) = the
  * reference's full GMRES.  Keeps the basis at m+1 vectors for long solves (config 5: 50M tets, PC_ILU0). */
 void KrylovSetRestart(Krylov* krylov, index_type m);

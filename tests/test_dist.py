@@ -87,3 +87,13 @@ def test_distributed_twolevel_gpu_gloo(world, oracle_lib):
     = P^T A P of the global matrix."""
     out = _launch("gpu_twolevel", world, 14, 0)
     assert "DIST_TWOLEVEL_OK" in out
+
+
+@pytest.mark.gpu
+def test_distributed_pipelined_gmres_gpu_gloo(oracle_lib):
+    """KrylovSetPipelined (p(1)-GMRES: one reduction per step, overlapped with the next matvec through the auxiliary basis
+    z = A M^-1 v) on a 2-way partition: residual history of the single-domain oracle at the loosened tolerance 1e-6 r0, same
+    solution, one all-reduce per step, no cancellation flag.  (The reduction's own stream is exercised by the RCCL
+    communicator test; the gloo callbacks are host-synchronous.)"""
+    out = _launch("gpu", 2, 8, 30, extra_env={"DFL_PIPELINED": "1"})
+    assert "DIST_GPU_OK" in out

@@ -500,3 +500,38 @@ def test_config4_coupled_step_at_size(api):
         alone.close()
         pc.close()
         P.close()
+
+
+def test_pipelined_gmres_single_gpu_matches_the_oracle_history(api, oracle_lib):
+    """KrylovSetPipelined on one GPU (no communicator: same arithmetic, nothing to overlap): 40 steps of the Jacobi-tree GMRES
+    follow the oracle's residual history to 1e-6 r0 (the z-recurrence and the Pythagorean norm cost accuracy: the
+    unpipelined solver holds 1e-10), the solution agrees to 1e-6, and switching the option off restores the exact path."""
+    m = kuhn_cube(8, jitter=0.2)
+    wg, dwg = synthetic_fields(m)
+    S = oracle_lib.System(m)
+    F, vals = S.assemble_system(wg, dwg, True, True)
+    xo, ho, r0o, ito = S.gmres(vals, F, maxit=40, atol=0.0, rtol=0.0)
+    L = api.lib()
+    P = api.Problem(m, maxit=40, atol=0.0, rtol=0.0)
+    try:
+        wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+        F_d, x_d = api.DeviceArray(6 * P.N), api.DeviceArray(6 * P.N)
+        P.assemble_system(wg_d, dwg_d, F_d, want_J=False)
+        P.assemble_system(wg_d, dwg_d, None, want_J=True)
+        it0, r00, h0, _ = P.solve(x_d, F_d)
+        assert np.abs(h0 - ho).max() <= 1e-9 * r0o
+        L.KrylovSetPipelined(P.ksp, 1)
+        x_d.zero()
+        it, r0, hist, _ = P.solve(x_d, F_d)
+        api.sync()
+        assert it == 40 and abs(r0 - r0o) <= 1e-12 * r0o
+        dev = np.abs(hist - ho).max() / r0o
+        assert dev <= 1e-6, dev
+        assert np.abs(x_d.numpy() - xo).max() <= 1e-6 * np.abs(xo).max()
+        assert not L.KrylovGetStats(P.ksp).contents.fused_norm_cancelled
+        L.KrylovSetPipelined(P.ksp, 0)
+        x_d.zero()
+        it2, r02, h2, _ = P.solve(x_d, F_d)
+        assert np.array_equal(h2, h0)
+    finally:
+        P.close()
