@@ -129,6 +129,19 @@ static void split(Ctx* x, index_type lo, index_type hi) {
         split(x, lo + half, hi);
     }
 }
+static index_type rank_to_pos(index_type r, index_type np, index_type pass, index_type nwave, int heavy_last) {
+    const index_type ps = r / pass, base = ps * pass;
+    const index_type in_pass = (np - base < pass) ? np - base : pass; /* positions of this pass */
+    const index_type nfull = in_pass / 32;                            /* its full chunks */
+    const index_type chunk = (r - base) >> 5;
+    if (!heavy_last) { /* round 2: full passes snake (even passes forward), the partial pass in rank order */
+        if (in_pass < pass) return r;
+        return base + ((ps & 1) ? nwave - 1 - chunk : chunk) * 32 + (r & 31);
+    }
+    if (chunk >= nfull) return r; /* the trailing partial chunk stays behind the full ones */
+    const index_type wv = (ps & 1) ? chunk : nfull - 1 - chunk;
+    return base + wv * 32 + (r & 31);
+}
 static index_type find_nz(const index_type* rp, const index_type* ci, index_type row, index_type col) {
     index_type lo = rp[row], hi = rp[row + 1] - 1;
     while (lo < hi) {
@@ -190,6 +203,7 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     if (nt > 16) nt = 16; /* a GPU box grants one rank a ~16-core share of a much wider host */
     if (nt < 1) nt = 1;
     const int verbose = getenv("DFL_PATCH_VERBOSE") != NULL;
+    const int heavy_last_g = getenv("DFL_SLOT_HEAVY_LAST") ? 1 : 0; /* A/B only: measured equal (2.17 against 2.16 ms, gpurun_out/r3h) */
     double t0 = omp_get_wtime();
 
     /* node -> (tet, a) lists, ascending tet inside a node */
@@ -371,8 +385,13 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
         for (index_type s = 0; s < ns; ++s)
             first_rank[s] = is_split[s] ? 4 * bsplit[maxc - cnt[s]]++ : 4 * nsplit + bsingle[maxc - cnt[s]]++;
         const index_type pass = DFL_SLOT_BLOCK / 2, nwave = DFL_SLOT_BLOCK / 64; /* lane pairs per pass over the positions; waves */
-        const index_type full = (np / pass) * pass;
-#define RANK_TO_POS(r) ((r) < full ? (((r) / pass) * pass + (((((r) / pass) & 1) ? nwave - 1 - (((r) % pass) >> 5) : (((r) % pass) >> 5)) * 32) + ((r) & 31)) : (r))
+        const int heavy_last = heavy_last_g;
+        /* rank -> position.  Ranks are dealt to the waves in chunks of 32 lane pairs: full passes in snake order, the partial
+           pass in rank order (heaviest chunk -- split slots, most contributions -- on wave 0).  DFL_SLOT_HEAVY_LAST=1 lays the
+           full chunks of a pass out in reverse wave order instead, so that the heaviest chunk does not share a wave with
+           phase 1 (waves 0 / 1): measured equal, kept for A/B -- the kernel is bound by none of its waves' instruction
+           streams (profiles/r03_pmc_lhs.txt). */
+#define RANK_TO_POS(r) rank_to_pos((r), np, pass, nwave, heavy_last)
         /* contribution counts in position order, then offsets */
         index_type* cpos = (index_type*)calloc((size_t)np + 1, sizeof(index_type));
         for (index_type s = 0; s < ns; ++s) {
