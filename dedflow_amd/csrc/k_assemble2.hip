@@ -20,11 +20,11 @@ namespace {
 
 constexpr int SBLK = DFL_SLOT_BLOCK;
 constexpr int SP_RV = 36;  // doubles of an LDS tet record in use: shg[12] conv[a][q] (16) tauM[4] | cT, w | sum tauM, cK (asm_device.hpp)
-// Record STRIDE: the lanes of a wave read the records of unrelated tets with 16-byte accesses.  At 36 doubles = 72 dwords the
-// start banks of two records differ by a multiple of 8: eight distinct starts, 51 % of the LDS cycles were bank conflicts
-// (profiles/r02e_pmc_lhs.txt).  38 doubles = 76 dwords = 4 x 19: the 16 possible starts of a 16-byte access are all
-// reached (start bank = 12 t mod 64), and 128 tets still fit four workgroups per CU (38.9 KB each).
-constexpr int SP_RS = 38;
+// Record stride = record size.  (A stride of 38 doubles -- all 16 start banks of a 16-byte access reachable instead of 8 --
+// left the bank-conflict count where it was, 2.5e8 of 5.0e8 LDS cycles, profiles/r03_pmc_lhs.txt: the lanes of a wave gather the
+// records of unrelated tets, a birthday problem whatever the stride.  120 tets x 288 B + the 4.5 KB of node records keep four
+// workgroups per CU.)
+constexpr int SP_RS = 36;
 
 typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
 
@@ -34,7 +34,7 @@ typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
 // before its row stores are issued, so neither phase waits on HBM and the row stores of patch p drain behind the work on
 // patch p+1.  (The first form staged offset / slot / descriptor lists in a double LDS buffer: three dependent LDS round trips
 // per slot before the first block evaluation and 45 KB of LDS per workgroup = 3 workgroups per CU; now 34 KB = 4.)
-__host__ __device__ inline size_t slot_lds_bytes(int max_tets) { return (size_t)max_tets * SP_RS * 8; }
+__host__ __device__ inline size_t slot_lds_bytes(int max_tets) { return (size_t)max_tets * SP_RS * 8 + (size_t)3 * DFL_SLOT_NODES * 16 + 16; }
 
 // first descriptor group of (pass, wave w) inside the patch: groups are stored pass-major, wave by wave, ceil(trips / 2) per
 // (pass, wave); trips: one byte per (pass, wave) in lo (pass 0) / hi (pass 1), at most 254
@@ -43,17 +43,6 @@ __device__ __forceinline__ int slot_first_group(unsigned lo, unsigned hi, int pa
     const unsigned glo = ((lo + 0x01010101u) >> 1) & 0x7f7f7f7fu, ghi = ((hi + 0x01010101u) >> 1) & 0x7f7f7f7fu;  // groups per byte
     const unsigned below = (1u << (8 * w)) - 1u;  // w = 0..3
     return pass ? slot_byte_sum(glo) + slot_byte_sum(ghi & below) : slot_byte_sum(glo & below);
-}
-
-__device__ __forceinline__ void slot_load_records(const T* __restrict__ nodep, const int4& nd, double2* r) {
-    const int node[4] = {nd.x, nd.y, nd.z, nd.w};
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {  // packed node record: x at [0..2], u at [3..5]
-        const double2* rp = reinterpret_cast<const double2*>(nodep + (long long)node[b] * 16);
-        r[3 * b] = rp[0];
-        r[3 * b + 1] = rp[1];
-        r[3 * b + 2] = rp[2];
-    }
 }
 
 // phase 1 of one tet: everything its sixteen (a,b) blocks share -> one LDS record
@@ -104,95 +93,172 @@ __device__ __forceinline__ void slot_tet_record(const double2* r, double* rec) {
     rec[35] = (4.0 * fact2 * kMU) * w;
 }
 
+// Developer timeline (probe build, dfl_tune_asm bit 2048): lane 0 of every wave of the first TRACE_WG workgroups stamps the
+// shader clock at nine points of each of its first TRACE_IT patches; tools/slot_timeline.py turns them into a per-phase budget.
+constexpr int TRACE_WG = 32, TRACE_IT = 48, TRACE_PT = 10;
+__device__ unsigned long long g_slot_trace[TRACE_WG * TRACE_IT * 4 * TRACE_PT];
+__device__ unsigned long long g_slot_wgtime[2048 * 2];  // per workgroup: cycles from entry to exit, patches walked
+#define SLOT_TR(k)                                                                                                    \
+    do {                                                                                                              \
+        if (PROBE && (dbg & 2048) && blockIdx.x < TRACE_WG && tr_it < TRACE_IT && (threadIdx.x & 63) == 0)             \
+            g_slot_trace[((blockIdx.x * TRACE_IT + tr_it) * 4 + (threadIdx.x >> 6)) * TRACE_PT + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+
+// Node records of a patch in LDS.  The tets touching a 7-node patch (~90) have ~55 distinct nodes; round 2 gathered four
+// records per (patch, tet) lane straight from HBM / L2 at the start of phase 1 (1080 16-byte requests per patch, their
+// latency -- 3000+ cycles of the 13 000 a patch takes, tools/slot_timeline.py -- exposed in every patch because keeping them
+// in flight across phase 2 costs 48 registers).  Now ONE lane per distinct node moves its (x, u) record -- 3 x 16 B -- by
+// LDS-DMA (global_load_lds_dwordx4: no destination registers) into s_nrec[piece][node], ONE PATCH AHEAD: issued right after
+// the barrier that ends phase 1 (nobody reads s_nrec any more), in flight during phase 2, retired by the issuing wave's own
+// s_waitcnt vmcnt(0) placed BEFORE its first row store of the patch (the counter is in order: a wait placed after the stores
+// would wait for their acknowledgement too), visible to everybody behind the end-of-patch barrier.  Phase 1 then reads its
+// four nodes by patch-local id (a byte each, host/slotpatch.c) from LDS.  165 requests per patch instead of 1080.
+typedef __attribute__((address_space(3))) char lds_char_t;
+__device__ __forceinline__ unsigned lds_byte_address(const void* p) { return (unsigned)(size_t)(lds_char_t*)p; }
+// one wave-instruction: lane l copies 16 B from its own global address to lds_dst + 16 l (lds_dst wave-uniform); hipcc does not
+// count this load: its completion is the caller's s_waitcnt vmcnt (cdna_hip_programming.md, inline-asm LDS-DMA recipe)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+constexpr int SP_NC = DFL_SLOT_NODES;  // node capacity of s_nrec
+constexpr int SP_CHUNK = 8;             // consecutive patches a workgroup claims at a time
+
+// the (x, u) records of the nodes nid (lane t: node t of the patch, t < nn) -> s_nrec; whole waves without a node skip
+__device__ __forceinline__ void slot_stage_nodes(const T* __restrict__ nodep, int nid, int nn, int tphys, unsigned nrec_base) {
+    const int w = __builtin_amdgcn_readfirstlane(tphys >> 6);
+    if (w * 64 >= nn) return;  // wave-uniform
+    if (tphys < nn) {
+        const T* src = nodep + (long long)nid * NREC;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) glds16(src + 2 * k, nrec_base + (unsigned)((k * SP_NC + w * 64) * 16));
+    }
+}
+
 // PROBE != 0 only under dfl_tune_asm (developer phase split: bit 0 skip phase 2, bit 1 skip phase 1, bit 2 skip the
-// block evaluation, bit 3 skip the store, 32 every lane reads tet record 0 = no LDS bank conflicts); the shipped
-// instantiation carries no probe branches
-// EARLY: the node records of the next patch are requested before phase 2 (they fly during it, at the price of 48 more
-// live registers: 2 waves per SIMD); otherwise after it (their latency is covered by the other resident workgroups)
-template <bool BETA0, int PROBE, bool EARLY>
-__global__ __launch_bounds__(SBLK, EARLY ? 2 : 4) void tet_lhs_slot_kernel(I P, const int4* __restrict__ hdr, const int4* __restrict__ ptet_ien,
-                                                           const I* __restrict__ slot_nz, const unsigned* __restrict__ ldesc,
-                                                           const T* __restrict__ nodep, T* __restrict__ val, T beta, int max_tets, int dbg_in) {
+// block evaluation, bit 3 skip the store, 32 every lane reads tet record 0 = no LDS bank conflicts, 2048 timeline); the
+// shipped instantiation carries no probe branches
+template <bool BETA0, int PROBE>
+__global__ __launch_bounds__(SBLK, 4) void tet_lhs_slot_kernel(I P, const int4* __restrict__ hdr, const unsigned* __restrict__ ptet_lid,
+                                                               const I* __restrict__ pnode, const I* __restrict__ slot_nz,
+                                                               const unsigned* __restrict__ ldesc, const T* __restrict__ nodep,
+                                                               T* __restrict__ val, T beta, int max_tets, int dbg_in,
+                                                               int* __restrict__ claim) {
     static_assert(SBLK == 256, "trip bytes: four waves x two passes");
     const int dbg = PROBE ? (dbg_in & ~(1 << 30)) : 0;
     extern __shared__ __attribute__((aligned(16))) double s_tet[];
+    const double2* const s_nrec = reinterpret_cast<const double2*>(s_tet + (size_t)max_tets * SP_RS);  // [3][SP_NC]
+    volatile int* const s_claim = reinterpret_cast<volatile int*>(s_tet + (size_t)max_tets * SP_RS + 6 * SP_NC);  // [4], behind s_nrec
+    const unsigned nrec_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte_address(s_nrec));
     // XCD-aware order: workgroup w runs on XCD w % 8; every XCD gets one contiguous range of the spatially ordered
-    // patches (neighbouring patches share tets and node records -> one L2), dealt round-robin to its workgroups
+    // patches (neighbouring patches share tets and node records -> one L2).  Inside that range the patches are CLAIMED, not
+    // dealt: the hardware issues from the oldest wave first, so of the four workgroups that share a CU the one launched first
+    // runs fastest -- with an equal static share each it was done after 2.75 M cycles, the last after 4.31 M, and for the last
+    // third of the kernel the CUs ran half empty (tools/slot_timeline.py, gpurun_out/r3j).  A workgroup's first CHUNK of
+    // SP_CHUNK consecutive patches is its own index; every further chunk comes from the XCD's counter, claimed two chunks
+    // ahead of its use, so neither the atomic nor the header loads behind it are ever waited for.  (One atomic per PATCH was
+    // tried first: device-scope atomics on one address retire every ~95 ns -- 36 000 of them per counter made the kernel
+    // 3.4 ms whatever else it did.)  Which workgroup takes which patch has no influence on the values: a patch's rows are
+    // summed by that patch alone, in a fixed order.
     const int per = (P + 7) >> 3;
     const int g8 = gridDim.x >> 3;
-    const int pbeg = (blockIdx.x & 7) * per;
+    const int xcd = blockIdx.x & 7;
+    const int pbeg = xcd * per;
     const int pend = min((int)P, pbeg + per);
-    int p = pbeg + (blockIdx.x >> 3);
+    const int base0 = pbeg + SP_CHUNK * (int)(blockIdx.x >> 3);  // chunk 0 of this workgroup
+    int p = base0;
     if (p >= pend) return;
-    // Role rotation (developer A/B, DFL_SLOT_ROTATION=1; off by default).  The four waves of a workgroup carry different loads:
-    // logical wave 0 runs phase 1 (90 tets fill waves 0 and 1), the positions with the most contributions and the split-slot
-    // reduction -- about 770 VALU instructions per patch against 316 for logical wave 3 -- and the counters say VALU busy 65 % =
-    // (770 + 700 + 316 + 316) / (4 x 770), as if wave i of every workgroup shared SIMD i with its like.  Rotating the roles
-    // between the workgroups of a CU (logical thread = physical thread + 64 rot) should then level the SIMDs; measured: 2.32 ms
-    // against 2.17 ms without (same box, gpurun_out/r3e), like round 2's alternation of the phase-1 half.  The hardware does not
-    // pin wave i to SIMD i; what bounds a patch is its heaviest wave's own dependent chain at a quarter share of a SIMD.
+    const int cbase = pbeg + SP_CHUNK * g8;  // claim c of this XCD = patches cbase + SP_CHUNK c ...
+    // the j-th patch of this workgroup (j / SP_CHUNK = chunk number: 0 static, the others claimed; s_claim is a ring of 4)
+#define SLOT_SEQ(j) (((j) < SP_CHUNK ? base0 : cbase + SP_CHUNK * __builtin_amdgcn_readfirstlane(s_claim[((j) / SP_CHUNK) & 3])) + ((j) % SP_CHUNK))
+    // Role rotation (developer A/B, DFL_SLOT_ROTATION=1; off by default): co-resident workgroups rotate which physical wave
+    // plays logical wave 0 (phase 1 + the heaviest positions).  Measured slower (2.32 against 2.17 ms, gpurun_out/r3e).
     const int rot = (dbg_in & (1 << 30)) ? (int)((blockIdx.x >> 8) & 3u) : 0;
     const int t = (int)((threadIdx.x + 64u * (unsigned)rot) & (unsigned)(SBLK - 1));
     const int lane = t & 63, pr = t >> 1;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int4 zero4 = make_int4(0, 0, 0, 0);
 
-    // ---- prologue: slot map and descriptors of the first patch, its connectivity ----------------------------------------
+    // ---- prologue: lists of the first patch, its node records staged and waited for ------------------------------------
     int4 h = hdr[2 * p], h2 = hdr[2 * p + 1];
     int nz0, nz1;
+    unsigned lid;
     unsigned d0a, d0b, d1a, d1b;  // descriptor groups 0, 1 of pass 0 and of pass 1 (two trips each)
     {
         const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(h2.y), hi = (unsigned)__builtin_amdgcn_readfirstlane(h2.z);
         const int g0 = slot_first_group(lo, hi, 0, w), g1 = slot_first_group(lo, hi, 1, w);
         const unsigned* lp = ldesc + (long long)__builtin_amdgcn_readfirstlane(h2.x) * 64 + lane;
+        const int nt0 = h.y & 0xffff, nn0 = h.y >> 16;
         nz0 = slot_nz[h.z + max(0, min(pr, h.w - 1))];
         nz1 = slot_nz[h.z + max(0, min(pr + SBLK / 2, h.w - 1))];
         d0a = lp[g0 * 64]; d0b = lp[g0 * 64 + 64];
         d1a = lp[g1 * 64]; d1b = lp[g1 * 64 + 64];
+        lid = ptet_lid[h.x + max(0, min(t, nt0 - 1))];
+        const int nid0 = pnode[h2.w + max(0, min(t, nn0 - 1))];
+        slot_stage_nodes(nodep, nid0, nn0, t, nrec_base);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    double2 r[12];
-    int4 nd = zero4;
-    if (t < h.y) nd = ptet_ien[h.x + t];
-    if (EARLY && t < h.y) slot_load_records(nodep, nd, r);
-    int pn = p + g8;
+    if (threadIdx.x == 0) s_claim[1] = atomicAdd(claim + xcd, 1);  // the second chunk of this workgroup
+    // the first patch's lists have arrived before the loop is entered: inside the loop the same registers carry the next
+    // patch's (already waited for), and the compiler merges the two states
+    asm volatile("" ::"v"(lid), "v"(nz0), "v"(nz1), "v"(d0a), "v"(d0b), "v"(d1a), "v"(d1b));
+    __syncthreads();  // s_nrec of the first patch is complete (every wave waited for its own LDS-DMA above); claims visible
+    int seq = 0;  // position of patch p in this workgroup's sequence
+    int pn = SLOT_SEQ(1);
+    int pnn = SLOT_SEQ(2);
     int4 hn = zero4, hn2 = zero4;
     if (pn < pend) { hn = hdr[2 * pn]; hn2 = hdr[2 * pn + 1]; }
-    // the first patch's lists have arrived before the loop is entered: inside the loop the same registers carry the next
-    // patch's (already waited for), and the compiler merges the two states -- without this it waits at the loop top for
-    // everything older than the new list loads, i.e. for the previous patch's row stores
-    asm volatile("" ::"v"(nd.x), "v"(nd.y), "v"(nd.z), "v"(nd.w), "v"(nz0), "v"(nz1), "v"(d0a), "v"(d0b), "v"(d1a), "v"(d1b));
 
+    int tr_it = 0;
+    const unsigned long long tr_begin = (PROBE && (dbg & 2048)) ? __builtin_readcyclecounter() : 0ull;
     for (;;) {
+        SLOT_TR(0);
         const bool has_next = pn < pend;
-        const int nt = h.y;
+        const int nt = h.y & 0xffff;
         const int np = __builtin_amdgcn_readfirstlane(h.w);
         const unsigned tlo = (unsigned)__builtin_amdgcn_readfirstlane(h2.y), thi = (unsigned)__builtin_amdgcn_readfirstlane(h2.z);
-        // (a) hop 2 for the next patch: connectivity of this lane's tet, slot map and descriptors, into registers.  Every load
-        // is unconditional (indices clamped into the patch; past the last patch the header is all zero and patch 0's first
-        // entries are read and dropped) and nothing is computed from the results here: the wave goes on to phase 1 with
-        // all of them in flight, and they are waited for right after phase 1 -- BEFORE this patch's row stores are issued,
-        // so that waiting for them never waits for a store
-        const int pnn = pn + g8;
+        // (a) the lists of the NEXT patch into registers: local node ids of this lane's tet, this lane's node of the node
+        // table, slot map and descriptors.  Every load is unconditional (indices clamped into the patch; past the last patch the
+        // header is all zero and patch 0's first entries are read and dropped) and nothing is computed from the results here
         int4 hnn = zero4, hnn2 = zero4;
         if (has_next && pnn < pend) { hnn = hdr[2 * pnn]; hnn2 = hdr[2 * pnn + 1]; }
+        const bool claims = (seq % SP_CHUNK) == 0;  // at the start of chunk c: claim chunk c + 2
+        int my_claim = 0;
+        if (claims && threadIdx.x == 0) my_claim = atomicAdd(claim + xcd, 1);
         const unsigned nlo = (unsigned)__builtin_amdgcn_readfirstlane(hn2.y), nhi = (unsigned)__builtin_amdgcn_readfirstlane(hn2.z);
         const int gn0 = slot_first_group(nlo, nhi, 0, w), gn1 = slot_first_group(nlo, nhi, 1, w);
         const unsigned* lpn = ldesc + (long long)__builtin_amdgcn_readfirstlane(hn2.x) * 64 + lane;
-        const int4 ndn = ptet_ien[hn.x + max(0, min(t, hn.y - 1))];
+        const int ntn = hn.y & 0xffff, nnn = hn.y >> 16;
+        const unsigned lidn = ptet_lid[hn.x + max(0, min(t, ntn - 1))];
+        const int nidn = pnode[hn2.w + max(0, min(t, nnn - 1))];
         const int nzn0 = slot_nz[hn.z + max(0, min(pr, hn.w - 1))];
         const int nzn1 = slot_nz[hn.z + max(0, min(pr + SBLK / 2, hn.w - 1))];
         const unsigned dn0a = lpn[gn0 * 64], dn0b = lpn[gn0 * 64 + 64];
         const unsigned dn1a = lpn[gn1 * 64], dn1b = lpn[gn1 * 64 + 64];
-        // (b) phase 1: one lane per (patch, tet)
+        // (b) phase 1: one lane per (patch, tet), node records from LDS by patch-local id
+        SLOT_TR(1);
         if (t < nt && !((PROBE & 2) && (dbg & 2))) {
-            if (!EARLY) slot_load_records(nodep, nd, r);
+            double2 r[12];
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) {
+                const int n = (int)((lid >> (8 * b4)) & 255u);
+                r[3 * b4] = s_nrec[n];
+                r[3 * b4 + 1] = s_nrec[SP_NC + n];
+                r[3 * b4 + 2] = s_nrec[2 * SP_NC + n];
+            }
             slot_tet_record(r, s_tet + t * SP_RS);
         }
-        __syncthreads();
+        SLOT_TR(2);
+        __syncthreads();  // tet records complete; nobody reads s_nrec any more
+        SLOT_TR(3);
         // (c) everything requested for the next patch has arrived
-        asm volatile("" ::"v"(ndn.x), "v"(ndn.y), "v"(ndn.z), "v"(ndn.w), "v"(nzn0), "v"(nzn1), "v"(dn0a), "v"(dn0b), "v"(dn1a), "v"(dn1b));
-        // hop 3 for the next patch (EARLY only): its node records fly during phase 2
-        if (EARLY && has_next && t < hn.y) slot_load_records(nodep, ndn, r);
+        asm volatile("" ::"v"(lidn), "v"(nidn), "v"(nzn0), "v"(nzn1), "v"(dn0a), "v"(dn0b), "v"(dn1a), "v"(dn1b));
+        SLOT_TR(4);
+        if (claims && threadIdx.x == 0) s_claim[(seq / SP_CHUNK + 2) & 3] = my_claim;  // (returned with the lists above); first read chunks later
+        // (d) the next patch's node records start their way into s_nrec; they land during phase 2
+        if (has_next) slot_stage_nodes(nodep, nidn, nnn, t, nrec_base);
+        bool dma_retired = !has_next;
 
         // ---- phase 2: one lane pair per slot position, two passes over the positions ---------------------------------------
         if (!((PROBE & 1) && (dbg & 1))) {
@@ -213,13 +279,8 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 4) void tet_lhs_slot_kernel(I P, 
                 double acc[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-#pragma nounroll
-                for (int k = 0; k < trips; ++k) {
-                    if (k >= 4 && !(k & 1)) dlo = lp[(gb + (k >> 1)) * 64];  // beyond the four prefetched trips (rare: > 8 contributions in a part)
-                    const unsigned d = dlo & 0xffffu;
-                    dlo = (dlo >> 16) | (dhi << 16);
-                    dhi >>= 16;
-                    if (d == 0xffffu) continue;
+                // one contribution: descriptor d = (local tet << 4) | (a << 2) | b, its block added to acc
+                auto contribute = [&](unsigned d) {
                     const int aa = (d >> 2) & 3, bb = d & 3;
                     const double* rec = s_tet + (((PROBE & 4) && (dbg & 32)) ? 0 : (d >> 4)) * SP_RS;  // probe 32: no bank conflicts
                     double ga[3], gb3[3], t0q[4], ca[4], cb[4];
@@ -240,7 +301,31 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 4) void tet_lhs_slot_kernel(I P, 
                     } else {
                         lhs_block_accumulate(aa == bb, ga, gb3, sc.y, sk.y, sc.x, sk.x, t0q, ca, cb, cb_a, ca_b, t0_b, acc);
                     }
+                };
+                // Up to four trips come out of the two prefetched descriptor words: NO memory instruction in that loop, so the
+                // compiler places no s_waitcnt vmcnt in it -- with a load inside (the refill below) it waits vmcnt(0) at the top
+                // of EVERY trip, i.e. the first trip of a patch waits for the LDS-DMA issued a moment ago, and the first trip of a
+                // second pass for the first pass's row stores.  More than four trips (a part of a slot with > 8 contributions:
+                // rare) take the general loop.
+                if (trips <= 4) {
+#pragma nounroll
+                    for (int k = 0; k < trips; ++k) {
+                        const unsigned d = dlo & 0xffffu;
+                        dlo = (dlo >> 16) | (dhi << 16);
+                        dhi >>= 16;
+                        if (d != 0xffffu) contribute(d);
+                    }
+                } else {
+#pragma nounroll
+                    for (int k = 0; k < trips; ++k) {
+                        if (k >= 4 && !(k & 1)) dlo = lp[(gb + (k >> 1)) * 64];
+                        const unsigned d = dlo & 0xffffu;
+                        dlo = (dlo >> 16) | (dhi << 16);
+                        dhi >>= 16;
+                        if (d != 0xffffu) contribute(d);
+                    }
                 }
+                if (pass == 0) SLOT_TR(5);
                 // reduce-scatter inside the pair: lane j ends up with the 16-byte pieces {j, j + 2, j + 4, j + 6} of the
                 // 128-byte line (entries 4k + 2j, 4k + 2j + 1) summed over both lanes, so that every store instruction
                 // of a pair covers one contiguous 32-byte sector
@@ -253,8 +338,8 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 4) void tet_lhs_slot_kernel(I P, 
                 // split slot (host/slotpatch.c): its four parts sit in four adjacent pairs (half a 16-lane DPP row, aligned);
                 // lane j of the first pair collects lane j of the others: (p0 + p1) + (p2 + p3), two row shifts.  The branch
                 // is on a WAVE-uniform condition: the split positions are ranked first, so in a 7-node patch they all sit in
-                // wave 0 and the other three waves skip the 32 DPP moves + 16 adds (left to the compiler the per-lane `if`
-                // became predicated code that every position paid for: 65 of the 116 instructions of this epilogue)
+                // one wave and the other three skip the 32 DPP moves + 16 adds (left to the compiler the per-lane `if` became
+                // predicated code that every position paid for: 65 of the 116 instructions of this epilogue)
                 if (__builtin_amdgcn_ballot_w64((nzr & 0xC0000000) != 0) != 0ull) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -266,6 +351,12 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 4) void tet_lhs_slot_kernel(I P, 
                         const double sx = dpp_quad<0x104>(e[k].x), sy = dpp_quad<0x104>(e[k].y);
                         if (nzr & 0xC0000000) { e[k].x += sx; e[k].y += sy; }
                     }
+                }
+                // this wave's LDS-DMA of the next patch's node records must be retired BEFORE the first row store: the
+                // counter is in order, a wait behind the stores would wait for their acknowledgement as well
+                if (!dma_retired) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    dma_retired = true;
                 }
                 if (nzr < 0) continue;  // followers of a split slot (and positions past the patch): only the first pair stores
                 if ((PROBE & 8) && (dbg & 8)) {
@@ -284,14 +375,29 @@ __global__ __launch_bounds__(SBLK, EARLY ? 2 : 4) void tet_lhs_slot_kernel(I P, 
                 for (int k = 0; k < 4; ++k) dst[2 * k] = e[k];
             }
         }
-        if (!has_next) break;
-        nd = ndn;
+        if (!dma_retired) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a wave without positions in this patch
+        SLOT_TR(6);
+        if (!has_next) {
+            if (PROBE && (dbg & 2048) && threadIdx.x == 0 && blockIdx.x < 2048) {
+                g_slot_wgtime[2 * blockIdx.x] = __builtin_readcyclecounter() - tr_begin;
+                g_slot_wgtime[2 * blockIdx.x + 1] = (unsigned long long)(tr_it + 1);
+            }
+            break;
+        }
+        lid = lidn;
         nz0 = nzn0; nz1 = nzn1;
         d0a = dn0a; d0b = dn0b; d1a = dn1a; d1b = dn1b;
-        __syncthreads();  // every wave is done with the tet records of this patch
+        __syncthreads();  // every wave is done with the tet records of this patch; s_nrec holds the next patch's nodes
+        SLOT_TR(7);
+        ++tr_it;
         h = hn; h2 = hn2; hn = hnn; hn2 = hnn2;
         p = pn; pn = pnn;
+        ++seq;
+        // the patch two ahead: the next one of its chunk, or (every SP_CHUNK-th time) the first one of a claimed chunk
+        if (((seq + 2) % SP_CHUNK) != 0) pnn = pnn + 1;
+        else pnn = SLOT_SEQ(seq + 2);
     }
+#undef SLOT_SEQ
 }
 
 // ====================================================================================
@@ -693,12 +799,24 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
 extern "C" {
 
 int dfl_lhs_slot_record_bytes(void) { return SP_RS * (int)sizeof(double); }
+// developer timeline of the slot kernel (probe build, dfl_tune_asm bit 2048): [TRACE_WG][TRACE_IT][4 waves][TRACE_PT] clock stamps
+int dfl_slot_wgtime_fetch(unsigned long long* out, int max_entries) {
+    if (max_entries < 4096) return -4096;
+    DFL_GUARD(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slot_wgtime), sizeof(unsigned long long) * 4096, 0, hipMemcpyDeviceToHost));
+    return 4096;
+}
+int dfl_slot_trace_fetch(unsigned long long* out, int max_entries) {
+    const int n = TRACE_WG * TRACE_IT * 4 * TRACE_PT;
+    if (max_entries < n) return -n;
+    DFL_GUARD(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slot_trace), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost));
+    return n;
+}
 int64_t dfl_lhs_slot_lds_bytes(I max_tets) { return (int64_t)slot_lds_bytes(max_tets); }
 
 extern int g_patch_dbg;
 int g_rhs_lane_grid_cap = 0;  // developer / test knob (dfl_tune(2, n)): few workgroups make a small mesh walk the pipelined loop
-void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const I* ptet_ien, const I* slot_nz, const uint32_t* ldesc,
-                               const T* nodep, T* val, T beta, I max_tets, void* stream) {
+void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const uint32_t* ptet_lid, const I* pnode, const I* slot_nz,
+                               const uint32_t* ldesc, const T* nodep, T* val, T beta, I max_tets, void* stream) {
     if (npatch <= 0) return;
     if (max_tets > SBLK) {
         fprintf(stderr, "dfl_assemble_tet_lhs_slot: patch limit exceeded (tets %d <= %d)\n", (int)max_tets, SBLK);
@@ -707,42 +825,35 @@ void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const I* ptet_ien, 
     const size_t lds = slot_lds_bytes(max_tets);
     // persistent grid: as many workgroups as the device keeps resident at this LDS size (re-derived when the size changes)
     static size_t lds_set = 0;
-    static int resident = 0, resident_early = 0;
+    static int resident = 0;
     if (lds != lds_set) {
-        const void* kernels[6] = {(const void*)tet_lhs_slot_kernel<true, 0, true>,  (const void*)tet_lhs_slot_kernel<false, 0, true>,
-                                  (const void*)tet_lhs_slot_kernel<true, 0, false>, (const void*)tet_lhs_slot_kernel<false, 0, false>,
-                                  (const void*)tet_lhs_slot_kernel<true, 15, true>, (const void*)tet_lhs_slot_kernel<true, 15, false>};
-        for (int k = 0; k < 6; ++k) DFL_GUARD(hipFuncSetAttribute(kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const void* kernels[3] = {(const void*)tet_lhs_slot_kernel<true, 0>, (const void*)tet_lhs_slot_kernel<false, 0>,
+                                  (const void*)tet_lhs_slot_kernel<true, 15>};
+        for (int k = 0; k < 3; ++k) DFL_GUARD(hipFuncSetAttribute(kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0, cus = 0, occ = 0;
         DFL_GUARD(hipGetDevice(&dev));
         DFL_GUARD(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (cus < 8) cus = 8;
-        DFL_GUARD(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernels[2], SBLK, lds));
-        resident = cus * (occ < 1 ? 1 : occ);
         DFL_GUARD(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernels[0], SBLK, lds));
-        resident_early = cus * (occ < 1 ? 1 : occ);
+        resident = cus * (occ < 1 ? 1 : occ);
         lds_set = lds;
-        if (getenv("DFL_PATCH_VERBOSE")) fprintf(stderr, "[slot kernel] %zu B LDS per workgroup, %d resident workgroups (%d EARLY) on %d CUs\n", lds, resident, resident_early, cus);
+        if (getenv("DFL_PATCH_VERBOSE")) fprintf(stderr, "[slot kernel] %zu B LDS per workgroup, %d resident workgroups on %d CUs\n", lds, resident, cus);
     }
-    // default: the late build; dfl_tune_asm bit 16 = EARLY (node records of the next patch requested before phase 2)
-    const bool early = (g_patch_dbg & 16) != 0;
-    const int probe = g_patch_dbg & ~16;  // any other bit: the probe build (always overwrites: beta = 0)
-    int grid = (early ? resident_early : resident) / 8 * 8;
-    const int need = 8 * ((npatch + 7) / 8);
+    const int probe = g_patch_dbg;  // any bit: the probe build (always overwrites: beta = 0)
+    int grid = resident / 8 * 8;
+    const int need = 8 * ((((npatch + 7) / 8) + SP_CHUNK - 1) / SP_CHUNK);  // every workgroup starts on a chunk of its own
     if (grid > need) grid = need;
     const int4* h4 = reinterpret_cast<const int4*>(hdr);
-    const int4* pi4 = reinterpret_cast<const int4*>(ptet_ien);
     static int rot_on = -1;  // DFL_SLOT_ROTATION=1: co-resident workgroups rotate the wave roles (A/B; slower, see the kernel)
     if (rot_on < 0) rot_on = getenv("DFL_SLOT_ROTATION") ? 1 : 0;
     const int kflags = probe | (rot_on ? (1 << 30) : 0);
-#define SLOT_LAUNCH(B0, PR, EA) tet_lhs_slot_kernel<B0, PR, EA><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, pi4, slot_nz, ldesc, nodep, val, beta, max_tets, kflags)
-    if (probe) {
-        if (early) SLOT_LAUNCH(true, 15, true); else SLOT_LAUNCH(true, 15, false);
-    } else if (beta == 0.0) {
-        if (early) SLOT_LAUNCH(true, 0, true); else SLOT_LAUNCH(true, 0, false);
-    } else {
-        if (early) SLOT_LAUNCH(false, 0, true); else SLOT_LAUNCH(false, 0, false);
-    }
+    static int* d_claim = nullptr;  // one patch counter per XCD, zeroed before every launch (stream-ordered)
+    if (!d_claim) DFL_GUARD(hipMalloc((void**)&d_claim, 8 * sizeof(int)));
+    DFL_GUARD(hipMemsetAsync(d_claim, 0, 8 * sizeof(int), S(stream)));
+#define SLOT_LAUNCH(B0, PR) tet_lhs_slot_kernel<B0, PR><<<grid, SBLK, lds, S(stream)>>>(npatch, h4, ptet_lid, pnode, slot_nz, ldesc, nodep, val, beta, max_tets, kflags, d_claim)
+    if (probe) SLOT_LAUNCH(true, 15);
+    else if (beta == 0.0) SLOT_LAUNCH(true, 0);
+    else SLOT_LAUNCH(false, 0);
 #undef SLOT_LAUNCH
     DFL_LAUNCH_CHECK();
 }

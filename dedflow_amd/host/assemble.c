@@ -198,7 +198,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
     }
     if (slot_lhs) { /* schedule 4: ONE launch, every nodal nonzero is summed in registers by its owner lanes (host/slotpatch.c) */
         const SlotPatchSched* ss = x->slotpatch;
-        DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_slot(ss->num_patch, ss->d_hdr, ss->d_ptet_ien, ss->d_slot_nz, ss->d_ldesc,
+        DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_slot(ss->num_patch, ss->d_hdr, ss->d_ptet_lid, ss->d_pnode, ss->d_slot_nz, ss->d_ldesc,
                                                              x->nodep, val, beta_J, ss->max_tets, s));
     }
     if (patch_rhs) { /* schedules 2, 3, 4: patch-staged residual, two launches, fixed summation order (host/patch.c) */

@@ -60,8 +60,11 @@ typedef struct SlotPatchSched {
     const CSRAttr* attr;
     index_type num_patch, max_tets, max_slots, max_contrib;
     int64_t total_tets;
-    int32_t* d_hdr;          /* device [num_patch][8]: tet_off, num_tet, pos_off, num_pos, group_off, trips_lo, trips_hi, 0 */
-    index_type* d_ptet_ien;  /* device [total_tets][4] node ids of every (patch, tet) pair */
+    int32_t* d_hdr;          /* device [num_patch][8]: tet_off, num_tet | num_node << 16, pos_off, num_pos, group_off, trips_lo, trips_hi, node_off */
+    uint32_t* d_ptet_lid;    /* device [total_tets]: the four patch-local node ids (a byte each) of every (patch, tet) pair */
+    index_type* d_pnode;     /* device [total_nodes]: global ids of every patch's distinct nodes, ascending inside a patch */
+    index_type max_nodes;
+    int64_t total_nodes;
     index_type* d_slot_nz;   /* device [positions] nodal nonzero of each slot position (+ split flags) */
     uint32_t* d_ldesc;       /* device lane-major descriptor groups: [group][64 lanes] x 2 x ((local tet << 4) | (a << 2) | b) */
 } SlotPatchSched;
@@ -152,7 +155,8 @@ void DflMatrixFSRelocateBlockValues(Matrix* m, value_type* new_val); /* host/mat
 value_type* DflMatrixFSScratchBlockBegin(Matrix* m); /* reference-layout (u,p) FS matrix -> scratch block array (host/matrix.c) */
 void DflMatrixFSScratchBlockEnd(Matrix* m);
 /* host/slotpatch.c */
-int DflSlotPatchLimitCheck(int64_t num_positions, int64_t num_tets, int64_t max_contributions_of_a_position, char* why, size_t why_len);
+int DflSlotPatchLimitCheck(int64_t num_positions, int64_t num_tets, int64_t num_nodes, int64_t max_contributions_of_a_position, char* why,
+                           size_t why_len);
 void DflSlotPatchSetTestLimits(int positions, int tets);
 
 #endif

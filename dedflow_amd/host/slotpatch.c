@@ -14,8 +14,12 @@
  * (geometry is recomputed from the node records, so moving meshes need no invalidation).
  *
  * Layout produced here (all device arrays):
- *   hdr[p]      = {tet_off, num_tet, pos_off, num_pos, group_off, trips_lo, trips_hi, 0}
- *   ptet_ien    [sum num_tet][4]  node ids of every (patch, tet) pair, ascending element id inside a patch
+ *   hdr[p]      = {tet_off, num_tet | num_node << 16, pos_off, num_pos, group_off, trips_lo, trips_hi, node_off}
+ *   pnode       [sum num_node]    global ids of the distinct nodes of the tets touching a patch, ascending: the kernel stages
+ *                                 their (x, u) records in LDS ONCE per patch -- one lane per node, LDS-DMA one patch ahead --
+ *                                 instead of gathering 4 records per (patch, tet) pair through L2 (~55 nodes against ~90 x 4)
+ *   ptet_lid    [sum num_tet]     the four patch-LOCAL node ids (one byte each) of every (patch, tet) pair, ascending element
+ *                                 id inside a patch (4 B instead of 16 B of global ids per pair: -0.36 GB per assembly at 10M tets)
  *   slot_nz     [positions]       nodal nonzero of every slot position; inside a patch the slots are sorted by contribution
  *                                 count (descending) and dealt to the waves in snake order, so that the 32 lane
  *                                 pairs of a wave see equal trip counts
@@ -44,7 +48,8 @@ typedef struct {
     const index_type* rp;  /* host nodal row pointer */
     const index_type* vp;  /* node -> tet list offsets */
     const index_type* ve;  /* tet*4 + a, ascending tet inside a node */
-    index_type leaf, cap, tcap;
+    const index_type* ien; /* connectivity (distinct nodes of a candidate patch) */
+    index_type leaf, cap, tcap, ncap;
     Range* out;
     index_type nout, capout;
 } Ctx;
@@ -69,10 +74,11 @@ static void emit(Ctx* x, index_type lo, index_type hi) {
         x->nout++;
     }
 }
-/* distinct tets touching the nodes idx[lo..hi) */
-static index_type count_tets(const Ctx* x, index_type lo, index_type hi) {
+/* distinct tets touching the nodes idx[lo..hi), and the distinct nodes of those tets (4096 / 16384 = "too many") */
+static index_type count_tets(const Ctx* x, index_type lo, index_type hi, index_type* num_nodes) {
     index_type tmp[4096];
     index_type m = 0;
+    *num_nodes = 16384;
     for (index_type i = lo; i < hi; ++i) {
         const index_type n = x->idx[i];
         for (index_type j = x->vp[n]; j < x->vp[n + 1]; ++j) {
@@ -83,7 +89,16 @@ static index_type count_tets(const Ctx* x, index_type lo, index_type hi) {
     qsort(tmp, (size_t)m, sizeof(index_type), cmp_i32);
     index_type u = 0;
     for (index_type i = 0; i < m; ++i)
-        if (i == 0 || tmp[i] != tmp[i - 1]) ++u;
+        if (i == 0 || tmp[i] != tmp[i - 1]) tmp[u++] = tmp[i];
+    if (u > 1024) return u;
+    index_type nd[4096];
+    for (index_type i = 0; i < u; ++i)
+        for (int a = 0; a < 4; ++a) nd[4 * i + a] = x->ien[(size_t)tmp[i] * 4 + a];
+    qsort(nd, (size_t)u * 4, sizeof(index_type), cmp_i32);
+    index_type v = 0;
+    for (index_type i = 0; i < 4 * u; ++i)
+        if (i == 0 || nd[i] != nd[i - 1]) ++v;
+    *num_nodes = v;
     return u;
 }
 static void split(Ctx* x, index_type lo, index_type hi) {
@@ -94,7 +109,9 @@ static void split(Ctx* x, index_type lo, index_type hi) {
         int64_t items = 0; /* (tet, owned node) pairs: 4 contributions each, at most 8 per lane of the workgroup */
         for (index_type i = lo; i < hi; ++i) items += x->vp[x->idx[i] + 1] - x->vp[x->idx[i]];
         /* + 3 positions per node: a diagonal slot (>= SPLIT_MIN contributions) is walked by four lane pairs */
-        if (n <= 1 || (slots + 3 * (int64_t)n <= x->cap && items <= 2 * DFL_SLOT_BLOCK && count_tets(x, lo, hi) <= x->tcap)) { emit(x, lo, hi); return; }
+        index_type nnode = 0;
+        if (n <= 1 || (slots + 3 * (int64_t)n <= x->cap && items <= 2 * DFL_SLOT_BLOCK && count_tets(x, lo, hi, &nnode) <= x->tcap &&
+                       nnode <= x->ncap)) { emit(x, lo, hi); return; }
     }
     f64 bl[3] = {1e300, 1e300, 1e300}, bh[3] = {-1e300, -1e300, -1e300};
     for (index_type i = lo; i < hi; ++i)
@@ -153,8 +170,9 @@ static index_type find_nz(const index_type* rp, const index_type* ci, index_type
 
 /* The shape limits of tet_lhs_slot_kernel (csrc/k_assemble2.hip) for ONE node patch: slot positions (one lane pair each, two
  * passes of DFL_SLOT_BLOCK / 2 pairs), tets touching the patch (one lane each in phase 1), trips of a lane pair (a header
- * byte).  0 = fits; otherwise the reason is written to `why`.  The recursive bisection stops at one node, so a single node
- * of very high valence (> 256 tets, or a row of > 252 nonzeros) is what can break them -- no cube mesh does, a mesh with a
+ * byte), distinct nodes of those tets (one lane each, staged in LDS).  0 = fits; otherwise the reason is written to `why`.  The
+ * recursive bisection stops at one node, so a single node of very high valence (> 256 tets, a row of > 252 nonzeros, > 64
+ * nodes around it) is what can break them -- no cube mesh does, a mesh with a
  * fan of hundreds of tets around one vertex does.  Host arithmetic only (tests/test_abi_cpu.py calls it without a GPU). */
 static int g_test_pos_limit = 0, g_test_tet_limit = 0;
 /* test hook: lower the limits (0 = the kernel's own) so that an ordinary mesh exercises the refusal and the fall-back */
@@ -162,7 +180,8 @@ void DflSlotPatchSetTestLimits(int positions, int tets) {
     g_test_pos_limit = positions;
     g_test_tet_limit = tets;
 }
-int DflSlotPatchLimitCheck(int64_t num_positions, int64_t num_tets, int64_t max_contributions_of_a_position, char* why, size_t why_len) {
+int DflSlotPatchLimitCheck(int64_t num_positions, int64_t num_tets, int64_t num_nodes, int64_t max_contributions_of_a_position, char* why,
+                           size_t why_len) {
     const int64_t pos_limit = g_test_pos_limit > 0 ? g_test_pos_limit : DFL_SLOT_BLOCK - 1;
     const int64_t tet_limit = g_test_tet_limit > 0 ? g_test_tet_limit : DFL_SLOT_BLOCK;
     if (num_positions > pos_limit) {
@@ -172,6 +191,10 @@ int DflSlotPatchLimitCheck(int64_t num_positions, int64_t num_tets, int64_t max_
     if (num_tets > tet_limit) {
         if (why) snprintf(why, why_len, "%lld tets touch one node patch (limit %lld)", (long long)num_tets, (long long)tet_limit);
         return 2;
+    }
+    if (num_nodes > DFL_SLOT_NODES) {
+        if (why) snprintf(why, why_len, "the tets touching one node patch have %lld distinct nodes (limit %d)", (long long)num_nodes, DFL_SLOT_NODES);
+        return 4;
     }
     if ((max_contributions_of_a_position + 1) / 2 > 254) {
         if (why) snprintf(why, why_len, "%lld contributions to one slot position (limit 508)", (long long)max_contributions_of_a_position);
@@ -220,7 +243,7 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     }
     index_type* idx = (index_type*)malloc(sizeof(index_type) * (size_t)N);
     for (index_type n = 0; n < N; ++n) idx[n] = n;
-    Ctx x = {xg, idx, rp, vp, ve, leaf, slot_cap, tet_cap, NULL, 0, 1024};
+    Ctx x = {xg, idx, rp, vp, ve, ien, leaf, slot_cap, tet_cap, DFL_SLOT_NODES, NULL, 0, 1024};
     x.out = (Range*)malloc(sizeof(Range) * (size_t)x.capout);
 #pragma omp parallel num_threads(nt)
 #pragma omp single
@@ -231,6 +254,8 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     /* pass 1: per-patch tet lists and sizes */
     index_type** tets_of = (index_type**)malloc(sizeof(index_type*) * (size_t)P);
     index_type* nt_of = (index_type*)malloc(sizeof(index_type) * (size_t)P);
+    index_type** nodes_of = (index_type**)malloc(sizeof(index_type*) * (size_t)P); /* distinct nodes of the patch's tets, ascending */
+    index_type* nn_of = (index_type*)malloc(sizeof(index_type) * (size_t)P);
 #pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
     for (index_type p = 0; p < P; ++p) {
         const index_type lo = x.out[p].lo, nn = x.out[p].hi - lo;
@@ -248,10 +273,18 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
             if (i == 0 || tl[i] != tl[i - 1]) tl[u++] = tl[i];
         tets_of[p] = tl;
         nt_of[p] = u;
+        index_type* nl = (index_type*)malloc(sizeof(index_type) * 4 * (size_t)(u > 0 ? u : 1));
+        for (index_type i = 0; i < u; ++i) memcpy(nl + 4 * (size_t)i, ien + (size_t)tl[i] * 4, 4 * sizeof(index_type));
+        qsort(nl, (size_t)u * 4, sizeof(index_type), cmp_i32);
+        index_type v = 0;
+        for (index_type i = 0; i < 4 * u; ++i)
+            if (i == 0 || nl[i] != nl[i - 1]) nl[v++] = nl[i];
+        nodes_of[p] = nl;
+        nn_of[p] = v;
     }
     int32_t* hdr = (int32_t*)calloc((size_t)P * 8 + 8, sizeof(int32_t));
-    int64_t tot_t = 0, tot_s = 0;
-    index_type maxt = 0, maxs = 0;
+    int64_t tot_t = 0, tot_s = 0, tot_n = 0;
+    index_type maxt = 0, maxs = 0, maxn = 0;
     int broken = 0;
     char why[160] = {0};
     for (index_type p = 0; p < P && !broken; ++p) {
@@ -265,17 +298,20 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
             if (c > maxc) maxc = c;
         }
         /* (the bisection honours the caps down to single nodes; a single node can still break the kernel's own limits) */
-        broken = DflSlotPatchLimitCheck(ns, nt_of[p], maxc, why, sizeof why);
+        broken = DflSlotPatchLimitCheck(ns, nt_of[p], nn_of[p], maxc, why, sizeof why);
         if (broken) {
             fprintf(stderr, "slot-owner schedule (assembly schedule 4) cannot hold this mesh: %s, around node %d\n", why, idx[x.out[p].lo]);
             break;
         }
         hdr[8 * p + 0] = (int32_t)tot_t;
-        hdr[8 * p + 1] = nt_of[p];
+        hdr[8 * p + 1] = nt_of[p] | (nn_of[p] << 16);
         hdr[8 * p + 2] = (int32_t)tot_s;
         hdr[8 * p + 3] = (int32_t)ns;
+        hdr[8 * p + 7] = (int32_t)tot_n;
         tot_t += nt_of[p];
         tot_s += ns;
+        tot_n += nn_of[p];
+        if (nn_of[p] > maxn) maxn = nn_of[p];
         if (nt_of[p] > maxt) maxt = nt_of[p];
         if (ns > maxs) maxs = (index_type)ns;
     }
@@ -284,17 +320,19 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
         broken = 4;
     }
     if (broken) {
-        for (index_type p = 0; p < P; ++p) free(tets_of[p]);
-        free(hdr); free(nt_of); free(tets_of); free(x.out); free(idx); free(ve); free(vp); free(ci); free(rp);
+        for (index_type p = 0; p < P; ++p) { free(tets_of[p]); free(nodes_of[p]); }
+        free(hdr); free(nt_of); free(tets_of); free(nn_of); free(nodes_of); free(x.out); free(idx); free(ve); free(vp); free(ci); free(rp);
         CdamFreeHost(ps, SIZE_OF(SlotPatchSched));
         return NULL;
     }
     ASSERT(tot_s >= spy->nnz);
     if (verbose)
         fprintf(stderr, "[slotpatch] %d patches (<= %d nodes / %d slots / %d tets): %.2f tets per patch-tet list entry per tet, max tets %d, "
-                        "max slots %d, %.2f s\n", P, leaf, slot_cap, tet_cap, (double)tot_t / (double)(T > 0 ? T : 1), maxt, maxs, omp_get_wtime() - t0);
+                        "max slots %d, distinct nodes per patch mean %.1f max %d, %.2f s\n", P, leaf, slot_cap, tet_cap,
+                (double)tot_t / (double)(T > 0 ? T : 1), maxt, maxs, (double)tot_n / (double)(P > 0 ? P : 1), maxn, omp_get_wtime() - t0);
 
-    index_type* ptet_ien = (index_type*)malloc(sizeof(index_type) * 4 * (size_t)(tot_t > 0 ? tot_t : 1));
+    uint32_t* ptet_lid = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(tot_t > 0 ? tot_t : 1));
+    index_type* pnode = (index_type*)malloc(sizeof(index_type) * (size_t)(tot_n > 0 ? tot_n : 1));
     index_type* slot_nz = (index_type*)malloc(sizeof(index_type) * (size_t)tot_s);
     index_type* coff = (index_type*)malloc(sizeof(index_type) * ((size_t)tot_s + 1));
     uint16_t* desc = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)T * 16);
@@ -319,7 +357,24 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
         index_type ns = 0; /* real slots (nodal nonzeros of the patch rows); hdr[8 p + 3] counts positions */
         for (index_type k = 0; k < nn; ++k) ns += rp[nodes[k] + 1] - rp[nodes[k]];
         const index_type* tl = tets_of[p];
-        for (index_type k = 0; k < ntp; ++k) memcpy(ptet_ien + ((size_t)hdr[8 * p] + k) * 4, ien + (size_t)tl[k] * 4, 4 * sizeof(index_type));
+        {   /* node table of the patch and the patch-local ids of its tets' vertices */
+            const index_type* nl = nodes_of[p];
+            const index_type nnp = nn_of[p];
+            memcpy(pnode + hdr[8 * p + 7], nl, sizeof(index_type) * (size_t)nnp);
+            for (index_type k = 0; k < ntp; ++k) {
+                uint32_t packed = 0;
+                for (int b = 0; b < 4; ++b) {
+                    const index_type g = ien[(size_t)tl[k] * 4 + b];
+                    index_type l = 0, h = nnp - 1;
+                    while (l < h) {
+                        const index_type mid = (l + h) >> 1;
+                        if (nl[mid] < g) l = mid + 1; else h = mid;
+                    }
+                    packed |= (uint32_t)l << (8 * b);
+                }
+                ptet_lid[(size_t)hdr[8 * p] + k] = packed;
+            }
+        }
         index_type* rowbase = (index_type*)malloc(sizeof(index_type) * (size_t)nn);
         index_type* cnt = (index_type*)calloc((size_t)ns, sizeof(index_type));
         index_type sb = 0;
@@ -433,6 +488,7 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
         index_type* pos_of = NULL;
         free(cpos); free(pos_of); free(bucket); free(ilt); free(islot); free(it); free(cnt); free(rowbase);
         free(tets_of[p]);
+        free(nodes_of[p]);
     }
     coff[tot_s] = (index_type)cbase[P];
     /* lane-major descriptor groups (see the layout comment): sizes, offsets, fill */
@@ -493,11 +549,15 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     ps->max_contrib = maxc_all;
     ps->total_tets = tot_t;
     ps->d_hdr = (int32_t*)CdamMallocDevice((ptrdiff_t)P * 8 * (ptrdiff_t)sizeof(int32_t) + 32);
-    ps->d_ptet_ien = (index_type*)CdamMallocDevice((ptrdiff_t)(tot_t > 0 ? tot_t : 1) * 4 * SIZE_OF(index_type));
+    ps->max_nodes = maxn;
+    ps->total_nodes = tot_n;
+    ps->d_ptet_lid = (uint32_t*)CdamMallocDevice((ptrdiff_t)(tot_t > 0 ? tot_t : 1) * (ptrdiff_t)sizeof(uint32_t) + 1024);
+    ps->d_pnode = (index_type*)CdamMallocDevice(((ptrdiff_t)tot_n + DFL_SLOT_BLOCK) * SIZE_OF(index_type));
     ps->d_slot_nz = (index_type*)CdamMallocDevice(((ptrdiff_t)tot_s + DFL_SLOT_BLOCK) * SIZE_OF(index_type));
     ps->d_ldesc = (uint32_t*)CdamMallocDevice((ptrdiff_t)ld_words * (ptrdiff_t)sizeof(uint32_t));
     HIPGUARD(hipMemcpy(ps->d_hdr, hdr, sizeof(int32_t) * 8 * (size_t)P, H2D));
-    HIPGUARD(hipMemcpy(ps->d_ptet_ien, ptet_ien, sizeof(index_type) * 4 * (size_t)tot_t, H2D));
+    HIPGUARD(hipMemcpy(ps->d_ptet_lid, ptet_lid, sizeof(uint32_t) * (size_t)tot_t, H2D));
+    HIPGUARD(hipMemcpy(ps->d_pnode, pnode, sizeof(index_type) * (size_t)tot_n, H2D));
     HIPGUARD(hipMemcpy(ps->d_slot_nz, slot_nz, sizeof(index_type) * (size_t)tot_s, H2D));
     HIPGUARD(hipMemcpy(ps->d_ldesc, ldesc, sizeof(uint32_t) * ld_words, H2D));
     if (verbose)
@@ -505,14 +565,14 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
                 100.0 * 16.0 * (double)T / (128.0 * (double)(gbase[P] > 0 ? gbase[P] : 1)));
     free(ldesc); free(gbase);
     if (verbose) fprintf(stderr, "[slotpatch] uploaded at %.2f s\n", omp_get_wtime() - t0);
-    free(cbase); free(desc); free(coff); free(slot_nz); free(ptet_ien); free(hdr); free(nt_of); free(tets_of);
+    free(cbase); free(desc); free(coff); free(slot_nz); free(ptet_lid); free(pnode); free(hdr); free(nt_of); free(tets_of); free(nn_of); free(nodes_of);
     free(x.out); free(idx); free(ve); free(vp); free(ci); free(rp);
     return ps;
 }
 
 void DflFreeSlotPatchSchedule(SlotPatchSched* ps) {
     if (!ps) return;
-    CdamFreeDevice(ps->d_hdr, 0); CdamFreeDevice(ps->d_ptet_ien, 0); CdamFreeDevice(ps->d_slot_nz, 0);
+    CdamFreeDevice(ps->d_hdr, 0); CdamFreeDevice(ps->d_ptet_lid, 0); CdamFreeDevice(ps->d_pnode, 0); CdamFreeDevice(ps->d_slot_nz, 0);
     CdamFreeDevice(ps->d_ldesc, 0);
     CdamFreeHost(ps, SIZE_OF(SlotPatchSched));
 }

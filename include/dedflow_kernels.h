@@ -336,21 +336,25 @@ void dfl_assemble_tet_lhs_rowpatch(dfl_index npatch, const dfl_index* p_ioff, co
                                    const dfl_value* egeo, const dfl_value* nodep, dfl_value* val, dfl_value beta,
                                    dfl_index max_slots, void* stream);
 /* slot-owner form (assembly schedule 4, default; host/slotpatch.c, csrc/k_assemble2.hip): workgroup p owns the CSR rows of
- * its node patch; hdr[p] = {tet_off, num_tet, pos_off, num_pos, group_off, trips_lo, trips_hi, 0}; ptet_ien[tet_off + k][4] =
- * node ids of the k-th tet touching the patch; position q of the patch (lane pair q % 128 in pass q / 128) is nodal nonzero
- * slot_nz[pos_off + q] & 0x3fffffff (bit 30 / 31: first / other part of a slot cut into four adjacent positions) and sums the
- * contributions its two lanes find in the lane-major descriptor groups ldesc (layout: host/slotpatch.c), each
- * (local tet << 4) | (a << 2) | b or 0xFFFF.  val = beta * val + assembled rows (beta = 0 overwrites).  max_tets = largest
- * num_tet over the patches (sizes the workgroup's LDS: dfl_lhs_slot_lds_bytes).  No atomics: bitwise reproducible. */
+ * its node patch; hdr[p] = {tet_off, num_tet | num_node << 16, pos_off, num_pos, group_off, trips_lo, trips_hi, node_off};
+ * pnode[node_off + n] = global id of the patch's n-th distinct node (ascending; every node of every tet touching the patch,
+ * <= DFL_SLOT_NODES); ptet_lid[tet_off + k] = the four LOCAL node ids (one byte each) of the k-th tet touching the patch;
+ * position q of the patch (lane pair q % 128 in pass q / 128) is nodal nonzero slot_nz[pos_off + q] & 0x3fffffff (bit 30 /
+ * 31: first / other part of a slot cut into four adjacent positions) and sums the contributions its two lanes find in the
+ * lane-major descriptor groups ldesc (layout: host/slotpatch.c), each (local tet << 4) | (a << 2) | b or 0xFFFF.
+ * val = beta * val + assembled rows (beta = 0 overwrites).  max_tets = largest num_tet over the patches (sizes the
+ * workgroup's LDS: dfl_lhs_slot_lds_bytes).  No atomics: bitwise reproducible. */
 #ifndef DFL_SLOT_BLOCK
 #define DFL_SLOT_BLOCK 256 /* threads of a slot-owner workgroup: caps a patch at this many tets and DFL_SLOT_BLOCK - 1 slot
                               positions (host/slotpatch.c builds to these caps) */
+#define DFL_SLOT_NODES 64  /* distinct nodes of the tets touching a patch: their (x, u) records are staged in LDS, one lane
+                              per node (3 x 16 B each, 3 KB) */
 #endif
 int dfl_lhs_slot_record_bytes(void);
 int64_t dfl_lhs_slot_lds_bytes(dfl_index max_tets);
-void dfl_assemble_tet_lhs_slot(dfl_index npatch, const int32_t* hdr, const dfl_index* ptet_ien, const dfl_index* slot_nz,
-                               const uint32_t* ldesc, const dfl_value* nodep, dfl_value* val, dfl_value beta,
-                               dfl_index max_tets, void* stream);
+void dfl_assemble_tet_lhs_slot(dfl_index npatch, const int32_t* hdr, const uint32_t* ptet_lid, const dfl_index* pnode,
+                               const dfl_index* slot_nz, const uint32_t* ldesc, const dfl_value* nodep, dfl_value* val,
+                               dfl_value beta, dfl_index max_tets, void* stream);
 /* wave-per-patch form of the residual (schedule 4): the padded layout of host/patch.c -- patch p holds tet slots
  * [p*pad_tets, ..) of lien / adj, node slots [p*pad_nodes, ..) of pnode / partial and adj_start[p*(pad_nodes+1) ..];
  * cnt[p] = num_tets | num_nodes << 16.  Supported shapes (pad_tets, pad_nodes): (16,32), (32,48), (64,64). */

@@ -87,16 +87,17 @@ def test_slot_patch_limits_fail_soft_cpu():
     from dedflow_amd import api
     L = api.lib()
     f = L.DflSlotPatchLimitCheck
-    f.restype, f.argtypes = C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_size_t]
+    f.restype, f.argtypes = C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_size_t]
     why = C.create_string_buffer(160)
-    assert f(126, 90, 6, why, 160) == 0                       # a 7-node patch of a cube mesh
-    assert f(255, 256, 508, why, 160) == 0                    # exactly at the limits
-    assert f(256, 10, 6, why, 160) == 1 and b"slot positions" in why.value
-    assert f(100, 257, 6, why, 160) == 2 and b"tets touch" in why.value
-    assert f(100, 100, 509, why, 160) == 3 and b"contributions" in why.value
+    assert f(126, 90, 50, 6, why, 160) == 0                       # a 7-node patch of a cube mesh
+    assert f(255, 256, 64, 508, why, 160) == 0                    # exactly at the limits
+    assert f(256, 10, 20, 6, why, 160) == 1 and b"slot positions" in why.value
+    assert f(100, 257, 20, 6, why, 160) == 2 and b"tets touch" in why.value
+    assert f(100, 100, 65, 6, why, 160) == 4 and b"distinct nodes" in why.value
+    assert f(100, 100, 50, 509, why, 160) == 3 and b"contributions" in why.value
     L.DflSlotPatchSetTestLimits.argtypes = [C.c_int, C.c_int]
     L.DflSlotPatchSetTestLimits(50, 20)
     try:
-        assert f(51, 10, 6, why, 160) == 1 and f(50, 21, 6, why, 160) == 2 and f(50, 20, 6, why, 160) == 0
+        assert f(51, 10, 9, 6, why, 160) == 1 and f(50, 21, 9, 6, why, 160) == 2 and f(50, 20, 9, 6, why, 160) == 0
     finally:
         L.DflSlotPatchSetTestLimits(0, 0)
