@@ -512,8 +512,16 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
                                                              const unsigned char* __restrict__ lien,
                                                              const unsigned short* __restrict__ sub4,
                                                              const unsigned short* __restrict__ sub_start,
-                                                             const T* __restrict__ nodep, T* __restrict__ partial, int dbg_in) {
+                                                             const T* __restrict__ nodep, T* __restrict__ partial, int dbg_in,
+                                                             unsigned long long* __restrict__ wtime) {
     const int dbg = PROBE ? dbg_in : 0;
+    // developer probe (DFL_RHS_WTIME=1, tools/rhs_wavetime.py): cycles and patches per persistent wave.  Finding (round 3): the
+    // workgroup launched first on a CU finishes its equal share after 1.35 M cycles, the second after 1.65 M (the hardware issues
+    // from the oldest wave first); claiming chunks of 8 patches from per-XCD counters levels that (1.64 / 1.72 M) but costs a
+    // memory operation and registers per iteration (18 spilled): 1.09 ms against 1.05 ms per F assembly -- not adopted here
+    // (it is in the J kernel, where a patch is 7x longer and the claim rides on an existing barrier).
+    const unsigned long long w_begin = wtime ? __builtin_readcyclecounter() : 0ull;
+    int w_patches = 0;
     constexpr int RS = NV + 1;                 // padded node record in LDS
     constexpr int NJ = (NODES * 7 + 63) / 64;  // 16-byte pieces of the node records per lane
     constexpr int OS = 260;                    // stride of one component of the parked results; slot 256 holds 0.0
@@ -781,6 +789,7 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
             if (!(PROBE && (dbg & 1024))) partial[n0 * 6 + k] = sum;
             else if (sum == 1.2345e300) partial[0] = sum;
         }
+        ++w_patches;
         if (!has_n) break;
         WAVE_SYNC();  // the sums are read: the slice and the lists take the next patch
         L1 = L2;
@@ -789,6 +798,10 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
         pn = pnn;
         L2 = L3;
         has_n = has_nn;
+    }
+    if (wtime && lane == 0) {
+        const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (gw < 4096) { wtime[2 * gw] = __builtin_readcyclecounter() - w_begin; wtime[2 * gw + 1] = (unsigned long long)w_patches; }
     }
 #undef G_LN
 #undef G_PART
@@ -814,6 +827,12 @@ int dfl_slot_trace_fetch(unsigned long long* out, int max_entries) {
 int64_t dfl_lhs_slot_lds_bytes(I max_tets) { return (int64_t)slot_lds_bytes(max_tets); }
 
 extern int g_patch_dbg;
+static unsigned long long* g_rhs_wtime = nullptr;
+int dfl_rhs_wtime_fetch(unsigned long long* out, int max_entries) {
+    if (!g_rhs_wtime || max_entries < 8192) return 0;
+    DFL_GUARD(hipMemcpy(out, g_rhs_wtime, 8192 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 8192;
+}
 int g_rhs_lane_grid_cap = 0;  // developer / test knob (dfl_tune(2, n)): few workgroups make a small mesh walk the pipelined loop
 void dfl_assemble_tet_lhs_slot(I npatch, const int32_t* hdr, const uint32_t* ptet_lid, const I* pnode, const I* slot_nz,
                                const uint32_t* ldesc, const T* nodep, T* val, T beta, I max_tets, void* stream) {
@@ -894,12 +913,18 @@ void dfl_assemble_tet_rhs_lane(I npatch, const I* cnt, const I* pnode, const uns
     const int need = 8 * ((((npatch + 7) / 8) + 3) / 4);  // one wave per patch of an XCD's share
     if (g > need) g = need;
     if (g_rhs_lane_grid_cap > 0 && g > g_rhs_lane_grid_cap) g = (g_rhs_lane_grid_cap + 7) / 8 * 8;
+    static unsigned long long* d_wtime = nullptr;  // DFL_RHS_WTIME=1: cycles and patches per wave (dfl_rhs_wtime_fetch)
+    if (!d_wtime && getenv("DFL_RHS_WTIME")) {
+        DFL_GUARD(hipMalloc((void**)&d_wtime, 8192 * sizeof(unsigned long long)));
+        DFL_GUARD(hipMemset(d_wtime, 0, 8192 * sizeof(unsigned long long)));
+        g_rhs_wtime = d_wtime;
+    }
     if (g_patch_dbg & ~(64 | 32))
-        tet_rhs_lane_kernel<64, 1, true><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, g_patch_dbg);
+        tet_rhs_lane_kernel<64, 1, true><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, g_patch_dbg, d_wtime);
     else if (wps == 2)
-        tet_rhs_lane_kernel<64, 2, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0);
+        tet_rhs_lane_kernel<64, 2, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0, d_wtime);
     else
-        tet_rhs_lane_kernel<64, 1, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0);
+        tet_rhs_lane_kernel<64, 1, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0, d_wtime);
     DFL_LAUNCH_CHECK();
 }
 
