@@ -335,8 +335,10 @@ __global__ __launch_bounds__(256) void rhs_node_sum_kernel(I N, const I* __restr
 }
 
 // gather layout: one line per node, written once per assembly call from the reference-layout vectors
+// nodexu != NULL: also the compact (x, u) records of the Jacobian kernel, 64 B per node (it reads nothing else of a node:
+// half the bytes per record fetched from HBM)
 __global__ __launch_bounds__(256) void pack_nodes_kernel(I N, const T* __restrict__ xg, const T* __restrict__ wg,
-                                                        const T* __restrict__ dwg, T* __restrict__ nodep) {
+                                                        const T* __restrict__ dwg, T* __restrict__ nodep, T* __restrict__ nodexu) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     double r[NREC];
@@ -356,6 +358,13 @@ __global__ __launch_bounds__(256) void pack_nodes_kernel(I N, const T* __restric
     double2* o = reinterpret_cast<double2*>(nodep + i * NREC);
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = make_double2(r[2 * k], r[2 * k + 1]);
+    if (nodexu) {
+        double2* c = reinterpret_cast<double2*>(nodexu + i * 8);
+        c[0] = make_double2(r[0], r[1]);
+        c[1] = make_double2(r[2], r[3]);
+        c[2] = make_double2(r[4], r[5]);
+        c[3] = make_double2(0.0, 0.0);
+    }
 }
 
 // F (reference layout) += packed residual; the packed buffer is cleared for the next call
@@ -884,10 +893,13 @@ void dfl_assemble_tet_rhs(I B, const I* ien_b, const T* nodep, T* Fp, void* stre
     DFL_LAUNCH_CHECK();
 }
 
-void dfl_pack_nodes(I N, const T* xg, const T* wg, const T* dwg, T* nodep, void* stream) {
+void dfl_pack_nodes2(I N, const T* xg, const T* wg, const T* dwg, T* nodep, T* nodexu, void* stream) {
     if (N <= 0) return;
-    pack_nodes_kernel<<<ceil_div(N, 256), 256, 0, S(stream)>>>(N, xg, wg, dwg, nodep);
+    pack_nodes_kernel<<<ceil_div(N, 256), 256, 0, S(stream)>>>(N, xg, wg, dwg, nodep, nodexu);
     DFL_LAUNCH_CHECK();
+}
+void dfl_pack_nodes(I N, const T* xg, const T* wg, const T* dwg, T* nodep, void* stream) {
+    dfl_pack_nodes2(N, xg, wg, dwg, nodep, nullptr, stream);
 }
 
 void dfl_unpack_rhs(I N, T* Fp, T* F, void* stream) {

@@ -36,13 +36,21 @@ typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
 // per slot before the first block evaluation and 45 KB of LDS per workgroup = 3 workgroups per CU; now 34 KB = 4.)
 __host__ __device__ inline size_t slot_lds_bytes(int max_tets) { return (size_t)max_tets * SP_RS * 8 + (size_t)3 * DFL_SLOT_NODES * 16 + 16; }
 
-// first descriptor group of (pass, wave w) inside the patch: groups are stored pass-major, wave by wave, ceil(trips / 2) per
-// (pass, wave); trips: one byte per (pass, wave) in lo (pass 0) / hi (pass 1), at most 254
+// Lane-major contribution descriptors (host/slotpatch.c).  Per (pass, wave) with T trips: floor(T / 2) groups of [64 lanes] x
+// one 32-bit word (trips 2g and 2g + 1) and, for odd T, a tail of [64 lanes] x u16 (32 words); offsets count in UNITS of one
+// trip = 32 words, so the first unit of (pass, wave w) is the sum of the trip bytes before it (one byte per (pass, wave) in lo
+// (pass 0) / hi (pass 1), at most 254 each).
 __device__ __forceinline__ int slot_byte_sum(unsigned x) { return (int)((x & 255u) + ((x >> 8) & 255u) + ((x >> 16) & 255u) + (x >> 24)); }
 __device__ __forceinline__ int slot_first_group(unsigned lo, unsigned hi, int pass, int w) {
-    const unsigned glo = ((lo + 0x01010101u) >> 1) & 0x7f7f7f7fu, ghi = ((hi + 0x01010101u) >> 1) & 0x7f7f7f7fu;  // groups per byte
     const unsigned below = (1u << (8 * w)) - 1u;  // w = 0..3
-    return pass ? slot_byte_sum(glo) + slot_byte_sum(ghi & below) : slot_byte_sum(glo & below);
+    return pass ? slot_byte_sum(lo) + slot_byte_sum(hi & below) : slot_byte_sum(lo & below);
+}
+// this lane's descriptor word of group g (trips 2g | 2g + 1 << 16; the tail: trip T - 1 in the low half, the high half is never
+// consumed) of a (pass, wave) with T trips whose first unit is u0; unconditional: past the last group it reads and drops
+__device__ __forceinline__ unsigned slot_desc_word(const unsigned* __restrict__ patch_desc, int u0, int g, int T, int lane) {
+    const bool tail = 2 * g + 1 == T;
+    const unsigned v = patch_desc[(u0 + 2 * g) * 32 + (tail ? (lane >> 1) : lane)];
+    return tail ? v >> (16 * (lane & 1)) : v;
 }
 
 // phase 1 of one tet: everything its sixteen (a,b) blocks share -> one LDS record
@@ -130,7 +138,7 @@ __device__ __forceinline__ void slot_stage_nodes(const T* __restrict__ nodep, in
     const int w = __builtin_amdgcn_readfirstlane(tphys >> 6);
     if (w * 64 >= nn) return;  // wave-uniform
     if (tphys < nn) {
-        const T* src = nodep + (long long)nid * NREC;
+        const T* src = nodep + (long long)nid * 8;  // compact record: x[3] u[3] pad pad
 #pragma unroll
         for (int k = 0; k < 3; ++k) glds16(src + 2 * k, nrec_base + (unsigned)((k * SP_NC + w * 64) * 16));
     }
@@ -188,12 +196,13 @@ __global__ __launch_bounds__(SBLK, 4) void tet_lhs_slot_kernel(I P, const int4* 
     {
         const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(h2.y), hi = (unsigned)__builtin_amdgcn_readfirstlane(h2.z);
         const int g0 = slot_first_group(lo, hi, 0, w), g1 = slot_first_group(lo, hi, 1, w);
-        const unsigned* lp = ldesc + (long long)__builtin_amdgcn_readfirstlane(h2.x) * 64 + lane;
+        const int T0 = (int)((lo >> (8 * w)) & 255u), T1 = (int)((hi >> (8 * w)) & 255u);
+        const unsigned* lp = ldesc + (long long)__builtin_amdgcn_readfirstlane(h2.x) * 32;
         const int nt0 = h.y & 0xffff, nn0 = h.y >> 16;
         nz0 = slot_nz[h.z + max(0, min(pr, h.w - 1))];
         nz1 = slot_nz[h.z + max(0, min(pr + SBLK / 2, h.w - 1))];
-        d0a = lp[g0 * 64]; d0b = lp[g0 * 64 + 64];
-        d1a = lp[g1 * 64]; d1b = lp[g1 * 64 + 64];
+        d0a = slot_desc_word(lp, g0, 0, T0, lane); d0b = slot_desc_word(lp, g0, 1, T0, lane);
+        d1a = slot_desc_word(lp, g1, 0, T1, lane); d1b = slot_desc_word(lp, g1, 1, T1, lane);
         lid = ptet_lid[h.x + max(0, min(t, nt0 - 1))];
         const int nid0 = pnode[h2.w + max(0, min(t, nn0 - 1))];
         slot_stage_nodes(nodep, nid0, nn0, t, nrec_base);
@@ -228,14 +237,15 @@ __global__ __launch_bounds__(SBLK, 4) void tet_lhs_slot_kernel(I P, const int4* 
         if (claims && threadIdx.x == 0) my_claim = atomicAdd(claim + xcd, 1);
         const unsigned nlo = (unsigned)__builtin_amdgcn_readfirstlane(hn2.y), nhi = (unsigned)__builtin_amdgcn_readfirstlane(hn2.z);
         const int gn0 = slot_first_group(nlo, nhi, 0, w), gn1 = slot_first_group(nlo, nhi, 1, w);
-        const unsigned* lpn = ldesc + (long long)__builtin_amdgcn_readfirstlane(hn2.x) * 64 + lane;
+        const int Tn0 = (int)((nlo >> (8 * w)) & 255u), Tn1 = (int)((nhi >> (8 * w)) & 255u);
+        const unsigned* lpn = ldesc + (long long)__builtin_amdgcn_readfirstlane(hn2.x) * 32;
         const int ntn = hn.y & 0xffff, nnn = hn.y >> 16;
         const unsigned lidn = ptet_lid[hn.x + max(0, min(t, ntn - 1))];
         const int nidn = pnode[hn2.w + max(0, min(t, nnn - 1))];
         const int nzn0 = slot_nz[hn.z + max(0, min(pr, hn.w - 1))];
         const int nzn1 = slot_nz[hn.z + max(0, min(pr + SBLK / 2, hn.w - 1))];
-        const unsigned dn0a = lpn[gn0 * 64], dn0b = lpn[gn0 * 64 + 64];
-        const unsigned dn1a = lpn[gn1 * 64], dn1b = lpn[gn1 * 64 + 64];
+        const unsigned dn0a = slot_desc_word(lpn, gn0, 0, Tn0, lane), dn0b = slot_desc_word(lpn, gn0, 1, Tn0, lane);
+        const unsigned dn1a = slot_desc_word(lpn, gn1, 0, Tn1, lane), dn1b = slot_desc_word(lpn, gn1, 1, Tn1, lane);
         // (b) phase 1: one lane per (patch, tet), node records from LDS by patch-local id
         SLOT_TR(1);
         if (t < nt && !((PROBE & 2) && (dbg & 2))) {
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(SBLK, 4) void tet_lhs_slot_kernel(I P, const int4* 
             const int j = t & 1;
             const bool hi1 = j != 0;
             const int g0 = slot_first_group(tlo, thi, 0, w), g1 = slot_first_group(tlo, thi, 1, w);
-            const unsigned* lp = ldesc + (long long)__builtin_amdgcn_readfirstlane(h2.x) * 64 + lane;
+            const unsigned* lp = ldesc + (long long)__builtin_amdgcn_readfirstlane(h2.x) * 32;
 #pragma nounroll
             for (int pass = 0; pass < 2; ++pass) {
                 const int trips = (int)(((pass ? thi : tlo) >> (8 * w)) & 255u);  // the same for the 32 pairs of this wave
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(SBLK, 4) void tet_lhs_slot_kernel(I P, const int4* 
                 } else {
 #pragma nounroll
                     for (int k = 0; k < trips; ++k) {
-                        if (k >= 4 && !(k & 1)) dlo = lp[(gb + (k >> 1)) * 64];
+                        if (k >= 4 && !(k & 1)) dlo = slot_desc_word(lp, gb, k >> 1, trips, lane);
                         const unsigned d = dlo & 0xffffu;
                         dlo = (dlo >> 16) | (dhi << 16);
                         dhi >>= 16;

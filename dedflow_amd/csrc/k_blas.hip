@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void scatter_idx_kernel(I n, const I* __restri
 __global__ __launch_bounds__(BLK) void alpha_states_kernel(I N, const T* __restrict__ wgold, const T* __restrict__ dwgold,
                                                           const T* __restrict__ dwg, T f1_0, T f1_1, T f2_0, T f2_1,
                                                           const T* __restrict__ xg, T* __restrict__ wga, T* __restrict__ dwga,
-                                                          T* __restrict__ nodep) {
+                                                          T* __restrict__ nodep, T* __restrict__ nodexu) {
     const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
     if (i >= N) return;
     const long long idx[6] = {3 * i, 3 * i + 1, 3 * i + 2, 3LL * N + i, 4LL * N + i, 5LL * N + i};
@@ -567,6 +567,13 @@ __global__ __launch_bounds__(BLK) void alpha_states_kernel(I N, const T* __restr
         o[5] = make_double2(d[2], d[3]);
         o[6] = make_double2(d[4], d[5]);
         o[7] = make_double2(0.0, 0.0);
+        if (nodexu) {  // the compact (x, u) records of the Jacobian kernel
+            double2* c = reinterpret_cast<double2*>(nodexu + i * 8);
+            c[0] = make_double2(x0, x1);
+            c[1] = make_double2(x2, w[0]);
+            c[2] = make_double2(w[1], w[2]);
+            c[3] = make_double2(0.0, 0.0);
+        }
     }
 }
 
@@ -625,11 +632,16 @@ void dfl_scatter_idx(I n, const I* idx, const T* in, T* x, void* stream) {
 
 
 
+void dfl_alpha_states2(I N, const T* wgold, const T* dwgold, const T* dwg, T f1_0, T f1_1, T f2_0, T f2_1, const T* xg, T* wgalpha,
+                       T* dwgalpha, T* nodep, T* nodexu, void* stream) {
+    if (N <= 0) return;
+    alpha_states_kernel<<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, wgold, dwgold, dwg, f1_0, f1_1, f2_0, f2_1, xg, wgalpha, dwgalpha, nodep,
+                                                                 nodexu);
+    DFL_LAUNCH_CHECK();
+}
 void dfl_alpha_states(I N, const T* wgold, const T* dwgold, const T* dwg, T f1_0, T f1_1, T f2_0, T f2_1, const T* xg, T* wgalpha,
                       T* dwgalpha, T* nodep, void* stream) {
-    if (N <= 0) return;
-    alpha_states_kernel<<<ceil_div(N, BLK), BLK, 0, S(stream)>>>(N, wgold, dwgold, dwg, f1_0, f1_1, f2_0, f2_1, xg, wgalpha, dwgalpha, nodep);
-    DFL_LAUNCH_CHECK();
+    dfl_alpha_states2(N, wgold, dwgold, dwg, f1_0, f1_1, f2_0, f2_1, xg, wgalpha, dwgalpha, nodep, nullptr, stream);
 }
 void dfl_alpha_predict(I N, T fac, T* dwg, void* stream) {
     if (N <= 0) return;

@@ -97,6 +97,7 @@ f64* DflMeshNodeRecords(Mesh3D* mesh) {
     if (!x->nodep) {
         const index_type N = Mesh3DNumNode(mesh);
         x->nodep = (f64*)CdamMallocDevice((ptrdiff_t)N * 16 * SIZE_OF(f64));
+        x->nodexu = (f64*)CdamMallocDevice((ptrdiff_t)N * 8 * SIZE_OF(f64));
         x->Fp = (f64*)CdamMallocDevice((ptrdiff_t)N * 8 * SIZE_OF(f64));
     }
     return x->nodep;
@@ -156,7 +157,8 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
     }
     /* packed gather records (one line per node) and packed residual accumulator */
     DflMeshNodeRecords(mesh);
-    if (!x->nodep_current) dfl_pack_nodes(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, x->nodep, s);
+    /* (the compact (x, u) copy only when a Jacobian follows: the residual kernels read the full records) */
+    if (!x->nodep_current) dfl_pack_nodes2(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, x->nodep, J ? x->nodexu : NULL, s);
     const b32 patch_lhs = J && x->cfg.sched_mode == 2;
     const b32 rowpatch_lhs = J && x->cfg.sched_mode == 3;
     const b32 slot_lhs = J && x->cfg.sched_mode == 4;
@@ -199,7 +201,7 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
     if (slot_lhs) { /* schedule 4: ONE launch, every nodal nonzero is summed in registers by its owner lanes (host/slotpatch.c) */
         const SlotPatchSched* ss = x->slotpatch;
         DFL_TIMED(DFL_TAG_ASM_LHS, dfl_assemble_tet_lhs_slot(ss->num_patch, ss->d_hdr, ss->d_ptet_lid, ss->d_pnode, ss->d_slot_nz, ss->d_ldesc,
-                                                             x->nodep, val, beta_J, ss->max_tets, s));
+                                                             x->nodexu, val, beta_J, ss->max_tets, s));
     }
     if (patch_rhs) { /* schedules 2, 3, 4: patch-staged residual, two launches, fixed summation order (host/patch.c) */
         const b32 wave = x->cfg.sched_mode >= 4; /* schedule 4: one wave per patch, padded layout */

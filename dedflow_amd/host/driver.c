@@ -50,8 +50,9 @@ void DflFreeFlowWork(FlowWork* fw) {
 static void alpha_states(Mesh3D* mesh, const f64* wgold, const f64* dwgold, const f64* dwg, f64* wgalpha, f64* dwgalpha) {
     const f64 fact1[] = {1.0 - kALPHAM, kALPHAM};
     const f64 fact2[] = {kDT * kALPHAF * (1.0 - kGAMMA), kDT * kALPHAF * kGAMMA};
-    dfl_alpha_states(Mesh3DNumNode(mesh), wgold, dwgold, dwg, fact1[0], fact1[1], fact2[0], fact2[1], Mesh3DDevice(mesh)->xg, wgalpha,
-                     dwgalpha, DflMeshNodeRecords(mesh), DflStream());
+    f64* const nodep = DflMeshNodeRecords(mesh); /* (allocates the compact (x, u) records of the Jacobian kernel as well) */
+    dfl_alpha_states2(Mesh3DNumNode(mesh), wgold, dwgold, dwg, fact1[0], fact1[1], fact2[0], fact2[1], Mesh3DDevice(mesh)->xg, wgalpha,
+                      dwgalpha, nodep, ((MeshExt*)mesh->ext)->nodexu, DflStream());
 }
 
 static void four_norms(FlowWork* fw, index_type N, const f64* F, f64* out, const DflComm* comm) {

@@ -107,6 +107,7 @@ typedef struct MeshExt {
     index_type* h_sched_elem;      /* host [T]: element id at each position of the execution schedule */
     f64* egeo_b;                   /* device [T][16] element geometry cache in schedule order (LHS kernel) */
     f64* nodep;                    /* device [N][16] packed gather records (x,u,phi,T,du,p,dphi,dT) */
+    f64* nodexu;                   /* device [N][8] compact (x,u) records: all the slot-owner Jacobian kernel reads of a node */
     f64* Fp;                       /* device [N][8] packed residual accumulator, zero between calls */
     RhsPatchSched* rhspatch;       /* RHS patch schedule (modes 2, 3), built on first use */
     RowPatchSched* rowpatch;       /* LHS row-owner patch schedule (mode 3), built on first use */

@@ -100,6 +100,7 @@ void Mesh3DDestroy(Mesh3D* m) {
         CdamFreeDevice(x->egeo_b, 0);
         if (x->h_sched_elem) CdamFreeHost(x->h_sched_elem, 0);
         CdamFreeDevice(x->nodep, 0);
+        CdamFreeDevice(x->nodexu, 0);
         CdamFreeDevice(x->Fp, 0);
         DflMeshFreeFaceLists(x);
         if (x->sched_offset) CdamFreeHost(x->sched_offset, 0);

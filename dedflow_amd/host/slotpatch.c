@@ -27,7 +27,9 @@
  *               belongs to pass q / 128, wave (q % 128) / 32, lane pair q % 32; lane 2 pair + j walks contributions j, j + 2,
  *               ... of the position's list (ascending local tet).  For every (pass, wave) of the patch, pass-major, with T =
  *               the largest trip count among the wave's 32 pairs (trips_lo / trips_hi: one byte per (pass, wave)):
- *               ceil(T / 2) groups of [64 lanes] x {trip 2g, trip 2g + 1} (one 32-bit word per lane and group).  The kernel
+ *               floor(T / 2) groups of [64 lanes] x {trip 2g, trip 2g + 1} (one 32-bit word per lane and group) and, for odd T, a
+ *               TAIL of [64 lanes] x {trip T - 1} (one u16 per lane: 32 words; round 2 padded it to a whole group, a quarter of
+ *               the descriptor bytes at the usual 3 trips).  Offsets count in units of one trip (32 words).  The kernel
  *               reads a lane's descriptors with coalesced word loads one patch ahead -- no offset list, no LDS staging.
  */
 #include <string.h>
@@ -512,7 +514,7 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
             const index_type trips = (maxc + 1) / 2;
             ASSERT(trips <= 254 && "slot-patch trip counts are bytes");
             tb[q >> 2] |= (uint32_t)trips << (8 * (q & 3));
-            groups += (trips + 1) / 2;
+            groups += trips; /* in UNITS of one trip = 64 lanes x u16 = 32 words */
         }
         hdr[8 * p + 5] = (int32_t)tb[0];
         hdr[8 * p + 6] = (int32_t)tb[1];
@@ -520,7 +522,7 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     }
     for (index_type p = 0; p < P; ++p) gbase[p + 1] += gbase[p];
     ASSERT(gbase[P] < 2147483647LL);
-    const size_t ld_words = ((size_t)gbase[P] + 4) * 64; /* + 4 groups: the kernel's clamped prefetch may read past the last group */
+    const size_t ld_words = ((size_t)gbase[P] + 8) * 32; /* + 8 units: the kernel's clamped prefetch may read past the last group */
     uint32_t* ldesc = (uint32_t*)malloc(sizeof(uint32_t) * ld_words);
     memset(ldesc, 0xff, sizeof(uint32_t) * ld_words);
 #pragma omp parallel for schedule(static) num_threads(nt)
@@ -532,15 +534,16 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
         for (index_type q = 0; q < 2 * nwave_blk; ++q) {
             const index_type trips = (index_type)((tb[q >> 2] >> (8 * (q & 3))) & 255u);
             const index_type first = (q / nwave_blk) * pass_pairs + (q % nwave_blk) * 32;
-            uint16_t* base = (uint16_t*)(ldesc + (size_t)g0 * 64);
+            uint16_t* base = (uint16_t*)(ldesc + (size_t)g0 * 32); /* u16 view: a full group = 128 entries, a tail = 64 */
             for (index_type k = first; k < first + 32 && k < np; ++k) {
                 const index_type c0 = coff[s0 + k], c = coff[s0 + k + 1] - c0;
                 for (index_type i = 0; i < c; ++i) { /* contribution i: lane 2 (k - first) + (i & 1), trip i / 2 */
-                    const index_type lane = 2 * (k - first) + (i & 1), trip = i >> 1;
-                    base[((size_t)(trip >> 1) * 64 + lane) * 2 + (trip & 1)] = desc[c0 + i];
+                    const index_type lane = 2 * (k - first) + (i & 1), trip = i >> 1, g = trip >> 1;
+                    if (2 * g + 1 == trips) base[(size_t)g * 128 + lane] = desc[c0 + i];               /* tail: one u16 per lane */
+                    else base[((size_t)g * 64 + lane) * 2 + (trip & 1)] = desc[c0 + i];                  /* word per lane: two trips */
                 }
             }
-            g0 += (trips + 1) / 2;
+            g0 += trips;
         }
     }
     ps->num_patch = P;
@@ -561,8 +564,8 @@ SlotPatchSched* DflBuildSlotPatchSchedule(Mesh3D* mesh, const CSRAttr* spy, inde
     HIPGUARD(hipMemcpy(ps->d_slot_nz, slot_nz, sizeof(index_type) * (size_t)tot_s, H2D));
     HIPGUARD(hipMemcpy(ps->d_ldesc, ldesc, sizeof(uint32_t) * ld_words, H2D));
     if (verbose)
-        fprintf(stderr, "[slotpatch] %.1f descriptor groups per patch, %.0f %% of their entries used\n", (double)gbase[P] / (double)(P > 0 ? P : 1),
-                100.0 * 16.0 * (double)T / (128.0 * (double)(gbase[P] > 0 ? gbase[P] : 1)));
+        fprintf(stderr, "[slotpatch] %.1f descriptor trips per patch, %.0f %% of their entries used\n", (double)gbase[P] / (double)(P > 0 ? P : 1),
+                100.0 * 16.0 * (double)T / (64.0 * (double)(gbase[P] > 0 ? gbase[P] : 1)));
     free(ldesc); free(gbase);
     if (verbose) fprintf(stderr, "[slotpatch] uploaded at %.2f s\n", omp_get_wtime() - t0);
     free(cbase); free(desc); free(coff); free(slot_nz); free(ptet_lid); free(pnode); free(hdr); free(nt_of); free(tets_of); free(nn_of); free(nodes_of);

@@ -69,6 +69,9 @@ void dfl_dscal_inv_dev(dfl_index n, const dfl_value* d_scale, dfl_value* x, void
 void dfl_alpha_states(dfl_index N, const dfl_value* wgold, const dfl_value* dwgold, const dfl_value* dwg, dfl_value f1_0,
                       dfl_value f1_1, dfl_value f2_0, dfl_value f2_1, const dfl_value* xg, dfl_value* wgalpha, dfl_value* dwgalpha,
                       dfl_value* nodep, void* stream);
+void dfl_alpha_states2(dfl_index N, const dfl_value* wgold, const dfl_value* dwgold, const dfl_value* dwg, dfl_value f1_0,
+                       dfl_value f1_1, dfl_value f2_0, dfl_value f2_1, const dfl_value* xg, dfl_value* wgalpha, dfl_value* dwgalpha,
+                       dfl_value* nodep /*or NULL*/, dfl_value* nodexu /*or NULL: compact (x, u) records*/, void* stream);
 void dfl_alpha_predict(dfl_index N, dfl_value fac, dfl_value* dwg, void* stream);
 void dfl_alpha_correct(dfl_index N, dfl_value c0, dfl_value c1, dfl_value* wgold, dfl_value* dwgold, const dfl_value* dwg, void* stream);
 void dfl_norms4(dfl_index N, const dfl_value* F, dfl_value* d_out4, int take_sqrt, dfl_value* work, void* stream);
@@ -299,6 +302,9 @@ dfl_index dfl_count_priority_ties(const dfl_index* ien, dfl_index T, const dfl_i
  *  dfl_unpack_rhs adds them to F in the reference layout and clears the packed buffer. */
 void dfl_pack_nodes(dfl_index N, const dfl_value* xg, const dfl_value* wgalpha, const dfl_value* dwgalpha /*or NULL*/,
                     dfl_value* nodep /*[N][16]*/, void* stream);
+/* the same, and (nodexu != NULL) the compact records of the Jacobian kernel: nodexu[i][8] = x[3] u[3] pad pad, 64 B per node */
+void dfl_pack_nodes2(dfl_index N, const dfl_value* xg, const dfl_value* wgalpha, const dfl_value* dwgalpha /*or NULL*/,
+                     dfl_value* nodep, dfl_value* nodexu /*or NULL*/, void* stream);
 void dfl_unpack_rhs(dfl_index N, dfl_value* Fp /*[N][8], zeroed on return*/, dfl_value* F, void* stream);
 /* per-element geometry cache (static mesh): egeo[e*16 + ..] = shape gradients[12], |det J|, sum G_ij^2, 1/tr G, pad;
  * `ien_x` is the connectivity in the order the consuming kernel walks (schedule or patch order) */
@@ -352,8 +358,9 @@ void dfl_assemble_tet_lhs_rowpatch(dfl_index npatch, const dfl_index* p_ioff, co
 #endif
 int dfl_lhs_slot_record_bytes(void);
 int64_t dfl_lhs_slot_lds_bytes(dfl_index max_tets);
+/* nodexu = the compact node records of dfl_pack_nodes2 ([N][8]: x[3] u[3] pad pad) */
 void dfl_assemble_tet_lhs_slot(dfl_index npatch, const int32_t* hdr, const uint32_t* ptet_lid, const dfl_index* pnode,
-                               const dfl_index* slot_nz, const uint32_t* ldesc, const dfl_value* nodep, dfl_value* val,
+                               const dfl_index* slot_nz, const uint32_t* ldesc, const dfl_value* nodexu, dfl_value* val,
                                dfl_value beta, dfl_index max_tets, void* stream);
 /* wave-per-patch form of the residual (schedule 4): the padded layout of host/patch.c -- patch p holds tet slots
  * [p*pad_tets, ..) of lien / adj, node slots [p*pad_nodes, ..) of pnode / partial and adj_start[p*(pad_nodes+1) ..];
