@@ -517,8 +517,8 @@ __device__ __forceinline__ LaneLists lane_load_lists(int pp, int lane, const I* 
 
 // PROBE (developer phase split under dfl_tune_asm): bit 128 skip the element pass, 256 skip the ordered sum, 512 skip the
 // record gather, 1024 skip the stores; the shipped instantiation carries none of these branches
-template <int NODES, int WPS, bool PROBE>  // WPS = waves per SIMD the registers are budgeted for (1: no spills; 2: 256 VGPRs)
-__global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __restrict__ cnt, const I* __restrict__ pnode,
+template <int NODES, int WPS, bool PROBE, int WPB = 4>  // WPB = waves per workgroup; WPS = waves per SIMD the registers are budgeted for (1: no spills; 2: 256 VGPRs)
+__global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const I* __restrict__ cnt, const I* __restrict__ pnode,
                                                              const unsigned char* __restrict__ lien,
                                                              const unsigned short* __restrict__ sub4,
                                                              const unsigned short* __restrict__ sub_start,
@@ -528,26 +528,37 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
     // developer probe (DFL_RHS_WTIME=1, tools/rhs_wavetime.py): cycles and patches per persistent wave.  Finding (round 3): the
     // workgroup launched first on a CU finishes its equal share after 1.35 M cycles, the second after 1.65 M (the hardware issues
     // from the oldest wave first); claiming chunks of 8 patches from per-XCD counters levels that (1.64 / 1.72 M) but costs a
-    // memory operation and registers per iteration (18 spilled): 1.09 ms against 1.05 ms per F assembly -- not adopted here
-    // (it is in the J kernel, where a patch is 7x longer and the claim rides on an existing barrier).
+    // memory operation and registers per iteration (18 spilled): 1.09 ms against 1.05 ms per F assembly -- not adopted; the
+    // WPB == 8 build claims from an LDS counter of its workgroup instead (below), which costs neither.
     const unsigned long long w_begin = wtime ? __builtin_readcyclecounter() : 0ull;
     int w_patches = 0;
     constexpr int RS = NV + 1;                 // padded node record in LDS
     constexpr int NJ = (NODES * 7 + 63) / 64;  // 16-byte pieces of the node records per lane
     constexpr int OS = 260;                    // stride of one component of the parked results; slot 256 holds 0.0
     constexpr int BUF = NODES * RS > 6 * OS ? NODES * RS : 6 * OS;
-    __shared__ __attribute__((aligned(16))) double s_buf[4][BUF];
-    __shared__ double s_subv[4][(128 + 4) * 6];  // sub-list sums, [sub-list][component]
-    __shared__ __attribute__((aligned(16))) unsigned short s_sub4[4][512];
-    __shared__ unsigned short s_st[4][NODES + 2];
+    __shared__ __attribute__((aligned(16))) double s_buf[WPB][BUF];
+    __shared__ double s_subv[WPB][(128 + 4) * 6];  // sub-list sums, [sub-list][component]
+    __shared__ __attribute__((aligned(16))) unsigned short s_sub4[WPB][512];
+    __shared__ unsigned short s_st[WPB][NODES + 2];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // w in an SGPR: patch ids,
                                                                                               // LDS bases scalar
     // XCD-aware persistent ranges: workgroup b runs on XCD b % 8; every XCD walks one contiguous range of patches
     const int per = (P + 7) >> 3;
     const int pbeg = (blockIdx.x & 7) * per;
     const int pend = min((int)P, pbeg + per);
-    const int wx = (gridDim.x >> 3) * 4;  // waves per XCD
-    int p = pbeg + (blockIdx.x >> 3) * 4 + w;
+    const int wx = (gridDim.x >> 3) * WPB;  // waves per XCD
+    // WPB == 8 (one workgroup per CU): the first two patches of a wave are its static ones, every later one is claimed from
+    // the workgroup's LDS counter -- item v of the workgroup is slot v % WPB of its round v / WPB, the same set of patches as
+    // the static walk.  The hardware issues from the OLDEST wave of a SIMD first, so of the two waves sharing a SIMD the one
+    // launched first finished an equal share after 1.35 M cycles and the other after 1.65 M; with the claim both run to the end.
+    constexpr bool CLAIM = WPB == 8;
+    __shared__ int s_next;
+    if (CLAIM) {
+        if (threadIdx.x == 0) s_next = 2 * WPB;
+        __syncthreads();
+    }
+    const int pwg = pbeg + (blockIdx.x >> 3) * WPB;
+    int p = pwg + w;
     if (p >= pend) return;  // whole waves leave; nothing below synchronises across waves
     double* const sb = s_buf[w];
 
@@ -740,8 +751,14 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
         // hop 2 of the next patch and hop 1 of the one after it, requested AFTER the element pass (their 40 registers are
         // free again) and in flight during the ordered sum; past the end of the range the loads are repeated on the last
         // patch and dropped: no branch around a load
+        int pnn = pn + wx;
+        if (CLAIM) {
+            int v = 0;
+            if (lane == 0) v = atomicAdd(&s_next, 1);
+            v = __builtin_amdgcn_readfirstlane(v);
+            pnn = pwg + (v / WPB) * wx + (v % WPB);
+        }
         gather(L2.nid);
-        const int pnn = pn + wx;
         const bool has_nn = pnn < pend;
         {
             const LaneLists T2 = lane_load_lists<NODES, false>(min(pn, pend - 1), lane, cnt, pnode, lien, sub4, sub_start);
@@ -810,7 +827,7 @@ __global__ __launch_bounds__(256, WPS) void tet_rhs_lane_kernel(I P, const I* __
         has_n = has_nn;
     }
     if (wtime && lane == 0) {
-        const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int gw = blockIdx.x * WPB + (threadIdx.x >> 6);
         if (gw < 4096) { wtime[2 * gw] = __builtin_readcyclecounter() - w_begin; wtime[2 * gw + 1] = (unsigned long long)w_patches; }
     }
 #undef G_LN
@@ -923,6 +940,7 @@ void dfl_assemble_tet_rhs_lane(I npatch, const I* cnt, const I* pnode, const uns
     const int need = 8 * ((((npatch + 7) / 8) + 3) / 4);  // one wave per patch of an XCD's share
     if (g > need) g = need;
     if (g_rhs_lane_grid_cap > 0 && g > g_rhs_lane_grid_cap) g = (g_rhs_lane_grid_cap + 7) / 8 * 8;
+    static const bool wpb8 = !(getenv("DFL_RHS_WPB") && atoi(getenv("DFL_RHS_WPB")) == 4);  // A/B: 4 = the static walk
     static unsigned long long* d_wtime = nullptr;  // DFL_RHS_WTIME=1: cycles and patches per wave (dfl_rhs_wtime_fetch)
     if (!d_wtime && getenv("DFL_RHS_WTIME")) {
         DFL_GUARD(hipMalloc((void**)&d_wtime, 8192 * sizeof(unsigned long long)));
@@ -931,7 +949,14 @@ void dfl_assemble_tet_rhs_lane(I npatch, const I* cnt, const I* pnode, const uns
     }
     if (g_patch_dbg & ~(64 | 32))
         tet_rhs_lane_kernel<64, 1, true><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, g_patch_dbg, d_wtime);
-    else if (wps == 2)
+    else if (wps == 2 && wpb8) {
+        // one workgroup of 8 waves per CU claiming patches from an LDS counter (see the kernel): 1.60 M cycles for the
+        // slowest wave against 1.72 M of two static 4-wave workgroups per CU (tools/ab_rhs_wpb.sh)
+        int g8 = cus / 8 * 8;
+        const int need8 = 8 * ((((npatch + 7) / 8) + 7) / 8);
+        if (g8 > need8) g8 = need8;
+        tet_rhs_lane_kernel<64, 2, false, 8><<<g8, 512, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0, d_wtime);
+    } else if (wps == 2)
         tet_rhs_lane_kernel<64, 2, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0, d_wtime);
     else
         tet_rhs_lane_kernel<64, 1, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0, d_wtime);
