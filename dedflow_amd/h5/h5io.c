@@ -152,6 +152,16 @@ void ArraySave(const Array* a, H5FileInfo* f, const char* name) {
     ASSERT(H5FileIsWritable(f) && "ArraySave: File is not writable");
     H5WriteDatasetf64(f, name, ArrayLen(a), ArrayData(a));
 }
+/* FieldLoad / FieldSave (Field.c:47-57): the dataset holds the host copy; a load refreshes the device copy */
+void FieldLoad(Field* f, H5FileInfo* h5f, const char* name) {
+    ASSERT(f && h5f && name && "FieldLoad: NULL pointer.");
+    ArrayLoad(FieldHost(f), h5f, name);
+    ArrayCopy(FieldDevice(f), FieldHost(f), H2D);
+}
+void FieldSave(const Field* f, H5FileInfo* h5f, const char* name) {
+    ASSERT(f && h5f && name && "FieldSave: NULL pointer.");
+    ArraySave(FieldHost(f), h5f, name);
+}
 void ParticleContextLoad(ParticleContext* ctx, H5FileInfo* f, const char* group) {
     char path[256];
     static const char* part[3] = {"coord", "vel", "acc"};

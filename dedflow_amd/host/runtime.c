@@ -400,7 +400,7 @@ void VecPointwiseDiv(const value_type* x, const value_type* y, value_type* z, in
 }
 void VecPointwiseInv(value_type* x, index_type n) { dfl_pointwise_inv(n, x, g_stream); }
 
-/* ---- Array.h (storage only; the reference's BLAS wrappers are dead on the path) ---- */
+/* ---- Array.h storage (the BLAS-1 wrappers and Field are in field.c) ---- */
 Array* ArrayCreateHost(index_type len) {
     Array* a = (Array*)CdamMallocHost(SIZE_OF(Array));
     a->is_host = TRUE;

@@ -586,6 +586,38 @@ void ArrayDestroy(Array* a);
 void ArrayCopy(Array* dst, const Array* src, MemCopyKind kind);
 void ArrayLoad(Array* a, H5FileInfo* h5f, const char* dataset_name);       /* Array.c:242-253; in libdedflow_h5.so */
 void ArraySave(const Array* a, H5FileInfo* h5f, const char* dataset_name); /* Array.c:255-261 */
+/* BLAS-1 wrappers of Array.h:24-36 (Array.c:83-238).  A device array runs the library's own kernels on the library stream and
+ * returns when the result is on the host / the array is updated, like the reference's cuBLAS calls with a host result pointer;
+ * a host array is walked on the host in index order, like the reference.  Both operands must live on the same side.
+ * ArrayZero is ArrayScale(a, 0.0) as in the reference (Array.c:103-105: a NaN stays a NaN).  SetAt with a repeated index keeps
+ * the LAST value, as the reference's sequential loop does.  The reference declares ArrayGetAt and defines ArrayAt: both names. */
+void ArraySet(Array* a, f64 val);
+void ArrayZero(Array* a);
+void ArraySetAt(Array* a, index_type n, const index_type* idx, const f64* val);
+void ArrayGetAt(const Array* a, index_type n, const index_type* idx, f64* val);
+void ArrayAt(const Array* a, index_type n, const index_type* idx, f64* val);
+void ArrayScale(Array* a, f64 val);
+void ArrayDot(f64* result, const Array* a, const Array* b);
+void ArrayNorm2(f64* result, const Array* a);
+void ArrayAXPY(Array* y, f64 a, const Array* x);
+void ArrayAXPBY(Array* y, f64 a, const Array* x, f64 b); /* y = a x + b y */
+
+/* ---- nodal fields (Field.h:13-33, Field.c:15-77): a host and a device Array of num_node * num_nodal_dof values ------- */
+typedef struct Field {
+    index_type shape[2];
+    Array* host;
+    Array* device;
+} Field;
+#define FieldHost(f) ((f)->host)
+#define FieldDevice(f) ((f)->device)
+Field* FieldCreate3D(const Mesh3D* mesh, i32 num_nodal_dof);
+void FieldDestroy(Field* f);
+void FieldInit(Field* f, void (*func)(f64*, void* ctx), void* ctx); /* func fills the host array; then H2D */
+void FieldLoad(Field* f, H5FileInfo* h5f, const char* group_name);       /* Field.c:47-51; in libdedflow_h5.so */
+void FieldSave(const Field* f, H5FileInfo* h5f, const char* group_name); /* Field.c:53-57 (saves the HOST copy) */
+void FieldCopy(Field* dst, const Field* src);
+void FieldUpdateHost(Field* f);
+void FieldUpdateDevice(Field* f);
 typedef struct ParticleContext {
     index_type num_particle;
     i32 num_pointwise_dof;
