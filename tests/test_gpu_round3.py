@@ -542,7 +542,8 @@ def test_array_blas_wrappers_and_field_vs_numpy(api, tmp_path):
     """Array.h:24-36 (Array.c:83-238) on host AND device arrays against numpy: Set / Zero / SetAt (repeated index keeps the last
     value) / GetAt / Scale / Dot / Norm2 / AXPY / AXPBY; Field.h:22-33 (Field.c:15-77): create on a mesh, Init through a
     callback, Copy, UpdateHost / UpdateDevice, Save / Load through libdedflow_h5.so.  Tolerance 1e-14 relative for the two
-    reductions (the device sums in a fixed two-stage tree, numpy pairwise); everything else bit-exact."""
+    reductions on the device (a fixed two-stage tree, numpy pairwise), 1e-12 on the host (index order, as the reference); AXPY /
+    AXPBY to one rounding; everything else bit-exact."""
     from dedflow_amd import h5
     L, H = api.lib(), h5.lib()
     L.Init(0, None)
@@ -590,10 +591,11 @@ def test_array_blas_wrappers_and_field_vs_numpy(api, tmp_path):
         x, xs = make(side, x0)
         y, ys = make(side, y0)
         r = f64()
+        tol = 1e-12 if side == "host" else 1e-14     # (the host side sums in index order like the reference: ~sqrt(n) eps)
         L.ArrayDot(C.byref(r), x, y)
-        assert abs(r.value - np.dot(x0, y0)) <= 1e-14 * np.abs(x0 * y0).sum(), side
+        assert abs(r.value - np.dot(x0, y0)) <= tol * np.abs(x0 * y0).sum(), side
         L.ArrayNorm2(C.byref(r), x)
-        assert abs(r.value - np.linalg.norm(x0)) <= 1e-14 * np.linalg.norm(x0), side
+        assert abs(r.value - np.linalg.norm(x0)) <= tol * np.linalg.norm(x0), side
         L.ArrayAXPY(y, 0.75, x)
         ref = y0 + 0.75 * x0
         got = read(y, ys)
