@@ -344,6 +344,14 @@ __global__ __launch_bounds__(256) void pack_nodes_kernel(I N, const T* __restric
     double r[NREC];
     r[0] = xg[3 * i]; r[1] = xg[3 * i + 1]; r[2] = xg[3 * i + 2];
     r[3] = wg[3 * i]; r[4] = wg[3 * i + 1]; r[5] = wg[3 * i + 2];
+    if (!nodep) {  // (uniform) a Jacobian-only call on the slot-owner schedule: the compact records are all that is read
+        double2* c = reinterpret_cast<double2*>(nodexu + i * 8);
+        c[0] = make_double2(r[0], r[1]);
+        c[1] = make_double2(r[2], r[3]);
+        c[2] = make_double2(r[4], r[5]);
+        c[3] = make_double2(0.0, 0.0);
+        return;
+    }
     r[6] = wg[4LL * N + i];
     r[7] = wg[5LL * N + i];
     if (dwg) {
@@ -364,6 +372,61 @@ __global__ __launch_bounds__(256) void pack_nodes_kernel(I N, const T* __restric
         c[1] = make_double2(r[2], r[3]);
         c[2] = make_double2(r[4], r[5]);
         c[3] = make_double2(0.0, 0.0);
+    }
+}
+
+// The same records written through LDS: a thread still reads its own node (coalesced reads of the reference-layout arrays) but
+// the wave writes its 64 records as 8 (full) / 4 (compact) store instructions of 1 KB of consecutive addresses each, instead
+// of 64 different lines per instruction.  LDS slice of a wave: piece k (16 B) of node n at [k * 65 + n].
+__global__ __launch_bounds__(256) void pack_nodes_lds_kernel(I N, const T* __restrict__ xg, const T* __restrict__ wg,
+                                                            const T* __restrict__ dwg, T* __restrict__ nodep, T* __restrict__ nodexu) {
+    __shared__ double2 s_rec[4][8 * 65];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long nb = (long long)blockIdx.x * 256 + w * 64;  // first node of the wave
+    const long long i = nb + lane;
+    double2* const sw = s_rec[w];
+    if (i < N) {
+        const double x0 = xg[3 * i], x1 = xg[3 * i + 1], x2 = xg[3 * i + 2];
+        const double u0 = wg[3 * i], u1 = wg[3 * i + 1], u2 = wg[3 * i + 2];
+        sw[lane] = make_double2(x0, x1);
+        sw[65 + lane] = make_double2(x2, u0);
+        sw[130 + lane] = make_double2(u1, u2);
+        if (nodep) {
+            double r[8];
+            r[0] = wg[4LL * N + i];
+            r[1] = wg[5LL * N + i];
+            if (dwg) {
+                r[2] = dwg[3 * i]; r[3] = dwg[3 * i + 1]; r[4] = dwg[3 * i + 2];
+                r[5] = dwg[3LL * N + i];  // pressure always from the rate vector (Q9, assemble.cu:1606-1609)
+                r[6] = dwg[4LL * N + i];
+                r[7] = dwg[5LL * N + i];
+            } else {
+                r[2] = r[3] = r[4] = r[5] = r[6] = r[7] = 0.0;
+            }
+            sw[195 + lane] = make_double2(r[0], r[1]);
+            sw[260 + lane] = make_double2(r[2], r[3]);
+            sw[325 + lane] = make_double2(r[4], r[5]);
+            sw[390 + lane] = make_double2(r[6], r[7]);
+            sw[455 + lane] = make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+    const long long left = N - nb;  // nodes of this wave that exist (may be <= 0 in the last block)
+    if (nodep) {
+        double2* o = reinterpret_cast<double2*>(nodep + nb * NREC);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int p = it * 64 + lane, n = p >> 3, k = p & 7;
+            if (n < left) o[p] = sw[k * 65 + n];
+        }
+    }
+    if (nodexu) {
+        double2* o = reinterpret_cast<double2*>(nodexu + nb * 8);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int p = it * 64 + lane, n = p >> 2, k = p & 3;
+            if (n < left) o[p] = k < 3 ? sw[k * 65 + n] : make_double2(0.0, 0.0);
+        }
     }
 }
 
@@ -880,6 +943,7 @@ void dfl_assemble_tet_rhs_patch(I npatch, const I* p_eoff, const I* p_noff, cons
 
 void dfl_rhs_node_sum(I N, const I* goff, const I* gidx, const T* partial, T* F, void* stream) {
     if (N <= 0) return;
+    // (three lanes per node, one 16-byte third of every partial record each: 0.147 against 0.138 ms -- not kept)
     rhs_node_sum_kernel<<<ceil_div(N, 256), 256, 0, S(stream)>>>(N, goff, gidx, partial, F);
     DFL_LAUNCH_CHECK();
 }
@@ -894,8 +958,10 @@ void dfl_assemble_tet_rhs(I B, const I* ien_b, const T* nodep, T* Fp, void* stre
 }
 
 void dfl_pack_nodes2(I N, const T* xg, const T* wg, const T* dwg, T* nodep, T* nodexu, void* stream) {
-    if (N <= 0) return;
-    pack_nodes_kernel<<<ceil_div(N, 256), 256, 0, S(stream)>>>(N, xg, wg, dwg, nodep, nodexu);
+    if (N <= 0 || (!nodep && !nodexu)) return;
+    static const bool direct = getenv("DFL_PACK_LDS") && atoi(getenv("DFL_PACK_LDS")) == 0;  // developer A/B
+    if (direct) pack_nodes_kernel<<<ceil_div(N, 256), 256, 0, S(stream)>>>(N, xg, wg, dwg, nodep, nodexu);
+    else pack_nodes_lds_kernel<<<ceil_div(N, 256), 256, 0, S(stream)>>>(N, xg, wg, dwg, nodep, nodexu);
     DFL_LAUNCH_CHECK();
 }
 void dfl_pack_nodes(I N, const T* xg, const T* wg, const T* dwg, T* nodep, void* stream) {

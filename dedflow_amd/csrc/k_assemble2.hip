@@ -517,13 +517,17 @@ __device__ __forceinline__ LaneLists lane_load_lists(int pp, int lane, const I* 
 
 // PROBE (developer phase split under dfl_tune_asm): bit 128 skip the element pass, 256 skip the ordered sum, 512 skip the
 // record gather, 1024 skip the stores; the shipped instantiation carries none of these branches
-template <int NODES, int WPS, bool PROBE, int WPB = 4>  // WPB = waves per workgroup; WPS = waves per SIMD the registers are budgeted for (1: no spills; 2: 256 VGPRs)
+// DIRECT: the node values are gathered from the caller's arrays (xg, and the reference-layout state vectors wg, dwg) as 14
+// 8-byte pieces per node instead of 7 16-byte pieces of a packed record: an F-only assembly call then needs no pack pass
+template <int NODES, int WPS, bool PROBE, int WPB = 4, bool DIRECT = false>  // WPB = waves per workgroup; WPS = waves per SIMD the registers are budgeted for (1: no spills; 2: 256 VGPRs)
 __global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const I* __restrict__ cnt, const I* __restrict__ pnode,
                                                              const unsigned char* __restrict__ lien,
                                                              const unsigned short* __restrict__ sub4,
                                                              const unsigned short* __restrict__ sub_start,
                                                              const T* __restrict__ nodep, T* __restrict__ partial, int dbg_in,
-                                                             unsigned long long* __restrict__ wtime) {
+                                                             unsigned long long* __restrict__ wtime, const T* __restrict__ xg = nullptr,
+                                                             const T* __restrict__ wg = nullptr, const T* __restrict__ dwg = nullptr,
+                                                             I Nn = 0) {
     const int dbg = PROBE ? dbg_in : 0;
     // developer probe (DFL_RHS_WTIME=1, tools/rhs_wavetime.py): cycles and patches per persistent wave.  Finding (round 3): the
     // workgroup launched first on a CU finishes its equal share after 1.35 M cycles, the second after 1.65 M (the hardware issues
@@ -562,11 +566,38 @@ __global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const 
     if (p >= pend) return;  // whole waves leave; nothing below synchronises across waves
     double* const sb = s_buf[w];
 
-    // the pieces of the node records this lane fetches: piece k = j * 64 + lane of node k / 7
-    double2 rv[NJ];
-#define G_LN(j) ((j * 64 + lane) / 7)
-#define G_PART(j) ((j * 64 + lane) - 7 * G_LN(j))
+    // the pieces of the node records this lane fetches: piece k = j * 64 + lane of node k / 7 (DIRECT: value k % 14 of node
+    // k / 14, in record order x(3) u(3) phi T du(3) p dphi dT -- pack_nodes_kernel's)
+    constexpr int NJR = DIRECT ? 2 * NJ : NJ;
+    double2 rv[DIRECT ? 1 : NJ];
+    double rd[DIRECT ? NJR : 1];
+#define G_LN(j) ((j * 64 + lv) / 7)
+#define G_PART(j) ((j * 64 + lv) - 7 * G_LN(j))
+#define D_LN(j) ((j * 64 + lv) / 14)
+#define D_Q(j) ((j * 64 + lv) - 14 * D_LN(j))
+    const long long bxg = (long long)xg, bwg = (long long)wg, bdw = (long long)dwg;
     auto gather = [&](int nid) {
+        if (DIRECT) {
+            int lv = lane;
+            asm volatile("" : "+v"(lv));  // the per-(lane, j) constants are recomputed here, not kept in 60 registers across the loop
+#pragma unroll
+            for (int j = 0; j < NJR; ++j) {
+                int node = __shfl(nid, D_LN(j) & 63, WAVE);
+                node = node < 0 ? 0 : node;
+                const int q = D_Q(j);
+                // x: xg[3n+q]; u: wg[3n+q-3]; phi, T: wg[(q-2)N+n]; du: dwg[3n+q-8]; p, dphi, dT: dwg[(q-8)N+n] -- as integer
+                // arithmetic on the three base addresses (a select among pointers becomes a lookup table in scratch)
+                const long long m3 = -(long long)(q >= 3), m8 = -(long long)(q >= 8);
+                const long long base = bxg + (m3 & (bwg - bxg)) + (m8 & (bdw - bwg));
+                const int sub = q - (int)(3 & m3) - (int)(5 & m8) + (q >= 6 && q < 8 ? 1 : 0);  // 0 1 2 | 0 1 2 | 4 5 | 0 1 2 | 3 4 5
+                const bool aos = sub < 3 && !(q >= 6 && q < 8);
+                const long long off = aos ? 3LL * node + sub : (long long)sub * Nn + node;
+                rd[j] = *reinterpret_cast<const T*>(base + 8 * off);
+            }
+            return;
+        }
+        int lv = lane;
+        if (WPB == 8) asm volatile("" : "+v"(lv));  // (as above; the 4-wave builds are kept as they were measured)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             int node = __shfl(nid, G_LN(j) & 63, WAVE);  // executed by every lane
@@ -577,12 +608,22 @@ __global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const 
     };
     auto stage = [&](const LaneLists& L) {  // registers -> the wave's LDS slice
         const int nn = L.c >> 16;
+        if (DIRECT) {
+            int lv = lane;
+            asm volatile("" : "+v"(lv));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            if (G_LN(j) < nn) {
-                sb[G_LN(j) * RS + 2 * G_PART(j)] = rv[j].x;
-                sb[G_LN(j) * RS + 2 * G_PART(j) + 1] = rv[j].y;
-            }
+            for (int j = 0; j < NJR; ++j)
+                if (D_LN(j) < nn) sb[D_LN(j) * RS + D_Q(j)] = rd[j];
+        } else {
+            int lv = lane;
+            if (WPB == 8) asm volatile("" : "+v"(lv));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (G_LN(j) < nn) {
+                    sb[G_LN(j) * RS + 2 * G_PART(j)] = rv[j].x;
+                    sb[G_LN(j) * RS + 2 * G_PART(j) + 1] = rv[j].y;
+                }
+        }
         reinterpret_cast<uint4*>(s_sub4[w])[lane] = L.sub;
         s_st[w][lane] = (unsigned short)L.st0;
         if (lane == 0) s_st[w][NODES] = (unsigned short)L.st1;
@@ -618,12 +659,12 @@ __global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const 
                 for (int b = 0; b < 4; ++b)
 #pragma unroll
                     for (int d = 0; d < 3; ++d) x[b * 3 + d] = r[b][d];
-                tet_geometry(x, invJ, detJ, shg);
+                tet_geometry_t<true>(x, invJ, detJ, shg);  // reciprocal / rsqrt: hardware seed + Newton (asm_device.hpp), as the J kernel
                 tet_metric(shg, G);
                 gg = 0.0;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) gg += G[k] * G[k];
-                itr = 1.0 / (G[0] + G[4] + G[8]);
+                itr = rcp_nr2(G[0] + G[4] + G[8]);
             }
             const double DS = SHA - SHB;
             const double fb[3] = {FB0, FB1, FB2};
@@ -672,8 +713,8 @@ __global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const 
                         t1 += v * v;
                     }
                     const double y = t1 + 3.0 * mu * mu * gg;
-                    const double tau0 = rsqrt(t0 + y) * (1.0 / kRHO);
-                    const double tau1 = y * rsqrt(y) * itr;
+                    const double tau0 = rsqrt_nr1(t0 + y) * (1.0 / kRHO);
+                    const double tau1 = y * rsqrt_nr1(y) * itr;
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const double xi = kRHO * (qd[i] - fb[i]) + kRHO * (uadv[0] - tau0 * rLi[0]) * grad[3 * i] +
@@ -726,8 +767,8 @@ __global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const 
                         const double v = shg[3 + rr] * uadv[0] + shg[6 + rr] * uadv[1] + shg[9 + rr] * uadv[2];
                         t1 += v * v;
                     }
-                    const double tau2 = rsqrt(t0 + t1);
-                    const double tau3 = rsqrt(t0 + t1 + 3.0 * kappa * kappa * gg) * (1.0 / (kRHO * kCP));
+                    const double tau2 = rsqrt_nr1(t0 + t1);
+                    const double tau3 = rsqrt_nr1(t0 + t1 + 3.0 * kappa * kappa * gg) * (1.0 / (kRHO * kCP));
                     const double bp = dphi + uadv[0] * grad[0] + uadv[1] * grad[1] + uadv[2] * grad[2];
                     const double btc = kRHO * kCP * (dT + uadv[0] * grad[3] + uadv[1] * grad[4] + uadv[2] * grad[5]);
                     SX[0] += bp;
@@ -832,6 +873,8 @@ __global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const 
     }
 #undef G_LN
 #undef G_PART
+#undef D_LN
+#undef D_Q
 }
 
 }  // namespace
@@ -925,9 +968,11 @@ void dfl_assemble_tet_rhs_wave(I npatch, I pad_tets, I pad_nodes, const I* cnt, 
 
 // lane-per-tet kernel, persistent waves: 2 workgroups per CU (built for 2 waves per SIMD; measured 0.85 ms at 10M tets against
 // 1.07 ms for the 1-wave build and 1.29 ms for the 4-lanes-per-tet wave kernel)
-void dfl_assemble_tet_rhs_lane(I npatch, const I* cnt, const I* pnode, const unsigned char* lien, const unsigned short* sub4,
-                               const unsigned short* sub_start, const T* nodep, T* partial, void* stream) {
+static void rhs_lane_launch(I npatch, const I* cnt, const I* pnode, const unsigned char* lien, const unsigned short* sub4,
+                            const unsigned short* sub_start, const T* nodep, T* partial, const T* xg, const T* wg, const T* dwg,
+                            I Nn, void* stream) {
     if (npatch <= 0) return;
+    const bool direct = nodep == nullptr;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -947,7 +992,7 @@ void dfl_assemble_tet_rhs_lane(I npatch, const I* cnt, const I* pnode, const uns
         DFL_GUARD(hipMemset(d_wtime, 0, 8192 * sizeof(unsigned long long)));
         g_rhs_wtime = d_wtime;
     }
-    if (g_patch_dbg & ~(64 | 32))
+    if ((g_patch_dbg & ~(64 | 32)) && !direct)
         tet_rhs_lane_kernel<64, 1, true><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, g_patch_dbg, d_wtime);
     else if (wps == 2 && wpb8) {
         // one workgroup of 8 waves per CU claiming patches from an LDS counter (see the kernel): 1.60 M cycles for the
@@ -955,12 +1000,29 @@ void dfl_assemble_tet_rhs_lane(I npatch, const I* cnt, const I* pnode, const uns
         int g8 = cus / 8 * 8;
         const int need8 = 8 * ((((npatch + 7) / 8) + 7) / 8);
         if (g8 > need8) g8 = need8;
-        tet_rhs_lane_kernel<64, 2, false, 8><<<g8, 512, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0, d_wtime);
+        if (direct)
+            tet_rhs_lane_kernel<64, 2, false, 8, true><<<g8, 512, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nullptr, partial, 0, d_wtime, xg, wg, dwg, Nn);
+        else
+            tet_rhs_lane_kernel<64, 2, false, 8><<<g8, 512, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0, d_wtime);
+    } else if (direct) {
+        fprintf(stderr, "dfl_assemble_tet_rhs_lane_direct: only the default 8-wave build gathers from the caller's arrays\n");
+        abort();
     } else if (wps == 2)
         tet_rhs_lane_kernel<64, 2, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0, d_wtime);
     else
         tet_rhs_lane_kernel<64, 1, false><<<g, 256, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0, d_wtime);
     DFL_LAUNCH_CHECK();
+}
+void dfl_assemble_tet_rhs_lane(I npatch, const I* cnt, const I* pnode, const unsigned char* lien, const unsigned short* sub4,
+                               const unsigned short* sub_start, const T* nodep, T* partial, void* stream) {
+    if (!nodep) { fprintf(stderr, "dfl_assemble_tet_rhs_lane: NULL node records\n"); abort(); }
+    rhs_lane_launch(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, nullptr, nullptr, nullptr, 0, stream);
+}
+void dfl_assemble_tet_rhs_lane_direct(I npatch, const I* cnt, const I* pnode, const unsigned char* lien, const unsigned short* sub4,
+                                      const unsigned short* sub_start, const T* xg, const T* wg, const T* dwg, I N, T* partial,
+                                      void* stream) {
+    if (!xg || !wg || !dwg) { fprintf(stderr, "dfl_assemble_tet_rhs_lane_direct: NULL input array\n"); abort(); }
+    rhs_lane_launch(npatch, cnt, pnode, lien, sub4, sub_start, nullptr, partial, xg, wg, dwg, N, stream);
 }
 
 }  // extern "C"

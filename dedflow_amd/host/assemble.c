@@ -158,11 +158,24 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
     /* packed gather records (one line per node) and packed residual accumulator */
     DflMeshNodeRecords(mesh);
     /* (the compact (x, u) copy only when a Jacobian follows: the residual kernels read the full records) */
-    if (!x->nodep_current) dfl_pack_nodes2(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, x->nodep, J ? x->nodexu : NULL, s);
     const b32 patch_lhs = J && x->cfg.sched_mode == 2;
     const b32 rowpatch_lhs = J && x->cfg.sched_mode == 3;
     const b32 slot_lhs = J && x->cfg.sched_mode == 4;
     const b32 patch_rhs = F && x->cfg.sched_mode >= 2;
+    /* Who reads which records: the slot-owner J kernel only the compact (x, u) ones, every other element kernel the full
+       ones; a Jacobian-only call on the default schedule therefore packs only the compact records.  (DFL_RHS_DIRECT=1, a
+       measured alternative: the lane-per-tet residual kernel gathers from the caller's arrays itself and a residual-only
+       call packs nothing -- 14 8-byte gathers per node cost the kernel more, 0.38 M of 1.28 M cycles per wave, than the
+       0.10 ms pack pass it saves: 1.01 against 0.96 ms per call.) */
+    static int rhs_direct_ok = -1;
+    if (rhs_direct_ok < 0) rhs_direct_ok = getenv("DFL_RHS_DIRECT") && atoi(getenv("DFL_RHS_DIRECT")) == 1;
+    const b32 lane_rhs = patch_rhs && x->cfg.sched_mode >= 4 && x->cfg.rhswave_tets == 64 && x->cfg.rhswave_nodes == 64 &&
+                         !dfl_tune_asm_flags();
+    const b32 rhs_direct = lane_rhs && rhs_direct_ok && dwgalpha_dptr && wgalpha_dptr && !x->nodep_current &&
+                           !(getenv("DFL_RHS_WPB") && atoi(getenv("DFL_RHS_WPB")) == 4);
+    const b32 need_full = (F && !rhs_direct) || (J && !slot_lhs);
+    if (!x->nodep_current)
+        dfl_pack_nodes2(N, dev->xg, wgalpha_dptr, dwgalpha_dptr, need_full ? x->nodep : NULL, slot_lhs ? x->nodexu : NULL, s);
     if (J && !slot_lhs && !x->egeo_b) { /* geometry cache in schedule order (static mesh), built once; the LHS kernels read it */
         x->egeo_b = (f64*)CdamMallocDevice((ptrdiff_t)mesh->num_tet * 16 * SIZE_OF(f64));
         dfl_elem_geometry(mesh->num_tet, x->ien_b, dev->xg, x->egeo_b, s);
@@ -214,7 +227,10 @@ void DflAssembleSystemTetBeta(Mesh3D* mesh, f64* wgalpha_dptr, f64* dwgalpha_dpt
                                : DflBuildRhsPatchSchedule(mesh, x->cfg.rhspatch_leaf, x->cfg.rhspatch_nodes, 0, 0);
         const RhsPatchSched* rp = x->rhspatch;
         int slot = DflProfileBegin(DFL_TAG_ASM_RHS);
-        if (wave && rp->d_sub4 && !(dfl_tune_asm_flags() & 32))
+        if (wave && rp->d_sub4 && rhs_direct)
+            dfl_assemble_tet_rhs_lane_direct(rp->num_patch, rp->d_cnt, rp->d_pnode, rp->d_lien, rp->d_sub4, rp->d_sub_start, dev->xg,
+                                             wgalpha_dptr, dwgalpha_dptr, N, rp->d_partial, s);
+        else if (wave && rp->d_sub4 && !(dfl_tune_asm_flags() & 32))
             dfl_assemble_tet_rhs_lane(rp->num_patch, rp->d_cnt, rp->d_pnode, rp->d_lien, rp->d_sub4, rp->d_sub_start, x->nodep,
                                       rp->d_partial, s);
         else if (wave)

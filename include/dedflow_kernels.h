@@ -302,7 +302,8 @@ dfl_index dfl_count_priority_ties(const dfl_index* ien, dfl_index T, const dfl_i
  *  dfl_unpack_rhs adds them to F in the reference layout and clears the packed buffer. */
 void dfl_pack_nodes(dfl_index N, const dfl_value* xg, const dfl_value* wgalpha, const dfl_value* dwgalpha /*or NULL*/,
                     dfl_value* nodep /*[N][16]*/, void* stream);
-/* the same, and (nodexu != NULL) the compact records of the Jacobian kernel: nodexu[i][8] = x[3] u[3] pad pad, 64 B per node */
+/* the same, and (nodexu != NULL) the compact records of the Jacobian kernel: nodexu[i][8] = x[3] u[3] pad pad, 64 B per node;
+ * nodep == NULL writes the compact records only (and reads only xg and the velocity part of wgalpha) */
 void dfl_pack_nodes2(dfl_index N, const dfl_value* xg, const dfl_value* wgalpha, const dfl_value* dwgalpha /*or NULL*/,
                      dfl_value* nodep, dfl_value* nodexu /*or NULL*/, void* stream);
 void dfl_unpack_rhs(dfl_index N, dfl_value* Fp /*[N][8], zeroed on return*/, dfl_value* F, void* stream);
@@ -373,6 +374,12 @@ void dfl_assemble_tet_rhs_wave(dfl_index npatch, dfl_index pad_tets, dfl_index p
 void dfl_assemble_tet_rhs_lane(dfl_index npatch, const dfl_index* cnt, const dfl_index* pnode, const unsigned char* lien,
                                const unsigned short* sub4, const unsigned short* sub_start, const dfl_value* nodep,
                                dfl_value* partial, void* stream);
+/* the same kernel gathering the node values from the caller's arrays (xg[N][3] and the reference-layout state vectors
+ * wgalpha / dwgalpha, all non-NULL) instead of packed records: a residual-only assembly call needs no pack pass */
+void dfl_assemble_tet_rhs_lane_direct(dfl_index npatch, const dfl_index* cnt, const dfl_index* pnode, const unsigned char* lien,
+                                      const unsigned short* sub4, const unsigned short* sub_start, const dfl_value* xg,
+                                      const dfl_value* wgalpha, const dfl_value* dwgalpha, dfl_index N, dfl_value* partial,
+                                      void* stream);
 /* developer probe of the patch kernel (bit 0 skip element loop, bit 1 skip flush, bit 2 skip LDS adds) */
 void dfl_tune_asm(int flags);
 int dfl_tune_asm_flags(void);
