@@ -519,7 +519,10 @@ __device__ __forceinline__ LaneLists lane_load_lists(int pp, int lane, const I* 
 // record gather, 1024 skip the stores; the shipped instantiation carries none of these branches
 // DIRECT: the node values are gathered from the caller's arrays (xg, and the reference-layout state vectors wg, dwg) as 14
 // 8-byte pieces per node instead of 7 16-byte pieces of a packed record: an F-only assembly call then needs no pack pass
-template <int NODES, int WPS, bool PROBE, int WPB = 4, bool DIRECT = false>  // WPB = waves per workgroup; WPS = waves per SIMD the registers are budgeted for (1: no spills; 2: 256 VGPRs)
+// SUM6: the ordered sum with one lane per sub-list / per node carrying all six components (16-byte LDS accesses on slot-major
+// results) instead of one lane per (sub-list, component) / (node, component): the same additions in the same order, 32 instead
+// of 72 LDS instructions per patch at level 1 and one trip instead of six at level 2
+template <int NODES, int WPS, bool PROBE, int WPB = 4, bool DIRECT = false, bool SUM6 = false>  // WPB = waves per workgroup; WPS = waves per SIMD the registers are budgeted for (1: no spills; 2: 256 VGPRs)
 __global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const I* __restrict__ cnt, const I* __restrict__ pnode,
                                                              const unsigned char* __restrict__ lien,
                                                              const unsigned short* __restrict__ sub4,
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const 
     constexpr int OS = 260;                    // stride of one component of the parked results; slot 256 holds 0.0
     constexpr int BUF = NODES * RS > 6 * OS ? NODES * RS : 6 * OS;
     __shared__ __attribute__((aligned(16))) double s_buf[WPB][BUF];
-    __shared__ double s_subv[WPB][(128 + 4) * 6];  // sub-list sums, [sub-list][component]
+    __shared__ __attribute__((aligned(16))) double s_subv[WPB][(128 + 4) * 6];  // sub-list sums, [sub-list][component]
     __shared__ __attribute__((aligned(16))) unsigned short s_sub4[WPB][512];
     __shared__ unsigned short s_st[WPB][NODES + 2];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // w in an SGPR: patch ids,
@@ -807,6 +810,53 @@ __global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const 
         }
         const LaneLists L3 = lane_load_lists<NODES, true>(min(pnn, pend - 1), lane, cnt, pnode, lien, sub4, sub_start);
         WAVE_SYNC();  // every lane is done with the node records: the slice now takes the per-(tet, vertex) results
+        if (SUM6) {
+            static_assert(!SUM6 || BUF >= 257 * 6, "slot-major results + the zero slot");
+            if (lane < ne) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {  // result slot lane * 4 + a: six components, 48 B
+                    double2* dst = reinterpret_cast<double2*>(sb + (lane * 4 + a) * 6);
+                    dst[0] = make_double2(out[a * 6], out[a * 6 + 1]);
+                    dst[1] = make_double2(out[a * 6 + 2], out[a * 6 + 3]);
+                    dst[2] = make_double2(out[a * 6 + 4], out[a * 6 + 5]);
+                }
+            }
+            if (lane < 6) sb[256 * 6 + lane] = 0.0;  // the slot the padding of a sub-list points at
+            WAVE_SYNC();
+            const int ns = (int)s_st[w][NODES];  // number of sub-lists (<= 128)
+            for (int sl = lane; sl < ns; sl += 64) {
+                const uint2 id = reinterpret_cast<const uint2*>(s_sub4[w])[sl];
+                const double2* p0 = reinterpret_cast<const double2*>(sb + (id.x & 0xffffu) * 6);
+                const double2* p1 = reinterpret_cast<const double2*>(sb + (id.x >> 16) * 6);
+                const double2* p2 = reinterpret_cast<const double2*>(sb + (id.y & 0xffffu) * 6);
+                const double2* p3 = reinterpret_cast<const double2*>(sb + (id.y >> 16) * 6);
+                double2* d = reinterpret_cast<double2*>(s_subv[w] + sl * 6);
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    const double2 v0 = p0[h], v1 = p1[h], v2 = p2[h], v3 = p3[h];
+                    d[h] = make_double2(((v0.x + v1.x) + v2.x) + v3.x, ((v0.y + v1.y) + v2.y) + v3.y);
+                }
+            }
+            WAVE_SYNC();
+            double2 f[3] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+            if (lane < nn) {
+                const int s1 = s_st[w][lane + 1];
+                for (int q = s_st[w][lane]; q < s1; ++q) {  // the node's 1-6 sub-list sums, in order
+                    const double2* v = reinterpret_cast<const double2*>(s_subv[w] + q * 6);
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) {
+                        const double2 t = v[h];
+                        f[h].x += t.x;
+                        f[h].y += t.y;
+                    }
+                }
+            }
+            // every lane stores its node's 48 bytes (zeros past the last node): a fixed number of unconditional stores
+            double2* dst = reinterpret_cast<double2*>(partial + (n0 + lane) * 6);
+            dst[0] = f[0];
+            dst[1] = f[1];
+            dst[2] = f[2];
+        } else {
         if (lane < ne) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -857,6 +907,7 @@ __global__ __launch_bounds__(64 * WPB, WPS) void tet_rhs_lane_kernel(I P, const 
             if (!(PROBE && (dbg & 1024))) partial[n0 * 6 + k] = sum;
             else if (sum == 1.2345e300) partial[0] = sum;
         }
+        }  // !SUM6
         ++w_patches;
         if (!has_n) break;
         WAVE_SYNC();  // the sums are read: the slice and the lists take the next patch
@@ -1000,8 +1051,11 @@ static void rhs_lane_launch(I npatch, const I* cnt, const I* pnode, const unsign
         int g8 = cus / 8 * 8;
         const int need8 = 8 * ((((npatch + 7) / 8) + 7) / 8);
         if (g8 > need8) g8 = need8;
+        static const bool sum6 = !(getenv("DFL_RHS_SUM6") && atoi(getenv("DFL_RHS_SUM6")) == 0);  // developer A/B
         if (direct)
-            tet_rhs_lane_kernel<64, 2, false, 8, true><<<g8, 512, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nullptr, partial, 0, d_wtime, xg, wg, dwg, Nn);
+            tet_rhs_lane_kernel<64, 2, false, 8, true, true><<<g8, 512, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nullptr, partial, 0, d_wtime, xg, wg, dwg, Nn);
+        else if (sum6)
+            tet_rhs_lane_kernel<64, 2, false, 8, false, true><<<g8, 512, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0, d_wtime);
         else
             tet_rhs_lane_kernel<64, 2, false, 8><<<g8, 512, 0, S(stream)>>>(npatch, cnt, pnode, lien, sub4, sub_start, nodep, partial, 0, d_wtime);
     } else if (direct) {
