@@ -35,3 +35,10 @@ for k in range(int(slot.max()) + 1):
     print("  workgroups launched %d-th on their CU: mean %.0f" % (k, c[slot == k].mean()))
 print("percentiles 0/25/50/75/100:", np.percentile(c, [0, 25, 50, 75, 100]).round())
 P.close()
+# per workgroup (= CU) and per XCD (workgroup b runs on XCD b % 8): is the spread between XCDs (static ranges) or between CUs?
+nw = 8 if os.environ.get("DFL_RHS_WPB", "8") != "4" else 4
+g = c[: len(c) // nw * nw].reshape(-1, nw).max(axis=1)
+print("per workgroup (slowest wave): mean %.0f min %.0f max %.0f" % (g.mean(), g.min(), g.max()))
+for x in range(8):
+    gx = g[x::8]
+    print("  XCD %d: %3d workgroups, mean %.0f min %.0f max %.0f" % (x, len(gx), gx.mean(), gx.min(), gx.max()))
