@@ -125,6 +125,7 @@ constexpr int CT = 8;
 constexpr int RPT = 4;                      // double2 slots per thread
 constexpr int ROWS_PER_BLOCK = BLK * RPT * 2;  // 2048 rows
 
+template <int MODE = 0>  // bit 1 = plain loads (developer A/B)
 __global__ __launch_bounds__(BLK) void cgs_dots_stage1(I n, I ncol, const T* __restrict__ Q, long long ldq,
                                                       const T* __restrict__ w, T* __restrict__ part, int nrb) {
     __shared__ double lds[4];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(BLK) void cgs_dots_stage1(I n, I ncol, const T* __r
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             double2 qv;
-            if (row[i] + 1 < n) qv = ld_stream(q + row[i]);
+            if (row[i] + 1 < n) qv = (MODE & 2) ? *reinterpret_cast<const double2*>(q + row[i]) : ld_stream(q + row[i]);
             else { qv.x = (row[i] < n) ? q[row[i]] : 0.0; qv.y = 0.0; }
             acc += qv.x * wv[i].x + qv.y * wv[i].y;
         }
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(BLK) void cgs_dots_stage2(int nrb, const T* part, T
 // w -= Q h (SUB) or y = Q c (!SUB); optional partial ||w||^2 per block
 constexpr int UPT = 2;  // double2 slots per thread
 constexpr int UROWS = BLK * UPT * 2;
-template <bool SUB>
+template <bool SUB, int MODE = 0>  // MODE (developer A/B, DFL_CGS_MODE): bit 0 = columns walked last to first, bit 1 = plain loads
 __global__ __launch_bounds__(BLK) void cgs_update_kernel(I n, I ncol, const T* __restrict__ Q, long long ldq,
                                                         const T* __restrict__ d_h, T* __restrict__ w, T* __restrict__ part) {
     __shared__ double lds[4];
@@ -186,13 +187,14 @@ __global__ __launch_bounds__(BLK) void cgs_update_kernel(I n, I ncol, const T* _
         } else { acc[i].x = 0.0; acc[i].y = 0.0; }
     }
 #pragma unroll 4
-    for (int j = 0; j < ncol; ++j) {
+    for (int jj = 0; jj < ncol; ++jj) {
+        const int j = (MODE & 1) ? ncol - 1 - jj : jj;
         const double h = (j < 128) ? sh[j] : d_h[j];
         const T* q = Q + (long long)j * ldq;
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
             double2 qv;
-            if (row[i] + 1 < n) qv = ld_stream(q + row[i]);
+            if (row[i] + 1 < n) qv = (MODE & 2) ? *reinterpret_cast<const double2*>(q + row[i]) : ld_stream(q + row[i]);
             else { qv.x = (row[i] < n) ? q[row[i]] : 0.0; qv.y = 0.0; }
             if (SUB) { acc[i].x -= qv.x * h; acc[i].y -= qv.y * h; }
             else { acc[i].x += qv.x * h; acc[i].y += qv.y * h; }
@@ -716,6 +718,20 @@ void dfl_dscal_inv_dev(I n, const T* d_scale, T* x, void* stream) {
     DFL_LAUNCH_CHECK();
 }
 
+static int cgs_mode() {
+    static int m = -1;
+    if (m < 0) m = getenv("DFL_CGS_MODE") ? atoi(getenv("DFL_CGS_MODE")) & 3 : 0;
+    return m;
+}
+#define CGS_UPDATE_LAUNCH(...)                                                                     \
+    do {                                                                                           \
+        switch (cgs_mode()) {                                                                      \
+            case 1: cgs_update_kernel<true, 1><<<g, BLK, 0, S(stream)>>>(__VA_ARGS__); break;      \
+            case 2: cgs_update_kernel<true, 2><<<g, BLK, 0, S(stream)>>>(__VA_ARGS__); break;      \
+            case 3: cgs_update_kernel<true, 3><<<g, BLK, 0, S(stream)>>>(__VA_ARGS__); break;      \
+            default: cgs_update_kernel<true, 0><<<g, BLK, 0, S(stream)>>>(__VA_ARGS__); break;     \
+        }                                                                                          \
+    } while (0)
 int64_t dfl_cgs_work_size(I n, I ncol) {
     int64_t nrb = ceil_div(n, ROWS_PER_BLOCK);
     int64_t a = nrb * (int64_t)(ncol > 0 ? ncol : 1);
@@ -726,13 +742,14 @@ void dfl_cgs_dots(I n, I ncol, const T* Q, int64_t ldq, const T* w, T* d_h, T* w
     if (ncol <= 0) return;
     int nrb = ceil_div(n, ROWS_PER_BLOCK);
     dim3 grid(nrb, ceil_div(ncol, CT));
-    cgs_dots_stage1<<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb);
+    if (cgs_mode() & 2) cgs_dots_stage1<2><<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb);
+    else cgs_dots_stage1<0><<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb);
     cgs_dots_stage2<<<ncol, BLK, 0, S(stream)>>>(nrb, work, d_h);
     DFL_LAUNCH_CHECK();
 }
 void dfl_cgs_update(I n, I ncol, const T* Q, int64_t ldq, const T* d_h, T* w, T* d_nrm, int take_sqrt, T* work, void* stream) {
     int g = ceil_div(n, UROWS);
-    cgs_update_kernel<true><<<g, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, d_h, w, d_nrm ? work : nullptr);
+    CGS_UPDATE_LAUNCH(n, ncol, Q, ldq, d_h, w, d_nrm ? work : nullptr);
     if (d_nrm) {
         if (take_sqrt) reduce_stage2<true><<<1, BLK, 0, S(stream)>>>(g, work, d_nrm);
         else reduce_stage2<false><<<1, BLK, 0, S(stream)>>>(g, work, d_nrm);
@@ -742,7 +759,7 @@ void dfl_cgs_update(I n, I ncol, const T* Q, int64_t ldq, const T* d_h, T* w, T*
 void dfl_cgs_update_givens(I n, I ncol, const T* Q, int64_t ldq, const T* d_h, T* w, T* d_nrm, T* work, I iter, T* d_H, I ldh,
                            T* d_gv, T* d_beta, T* d_res_hist, void* stream) {
     int g = ceil_div(n, UROWS);
-    cgs_update_kernel<true><<<g, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, d_h, w, work);
+    CGS_UPDATE_LAUNCH(n, ncol, Q, ldq, d_h, w, work);
     norm_givens_kernel<<<1, BLK, 0, S(stream)>>>(g, work, d_nrm, iter, d_H, ldh, d_gv, d_beta, d_res_hist);
     DFL_LAUNCH_CHECK();
 }

@@ -299,6 +299,84 @@ def run_gpu_step(rank, world, M, its):
     P.close()
 
 
+def run_gpu_transient_twolevel(rank, world, M, its):
+    """BASELINE config 5 in small: a TRANSIENT (its = number of time steps, 2 Newton iterations each) on the partitioned mesh
+    with PC_TWOLEVEL under FGMRES, against the same transient on the whole mesh in one process (product path, same
+    preconditioner, both solved to rtol 1e-8 so that the states are comparable): Newton iteration counts equal, every solve
+    converged, initial Newton residuals and the states after the last step equal at solver accuracy."""
+    import torch
+    import torch.distributed as dist
+    from dedflow_amd import api, dist_bench
+    from dedflow_amd import dist as D
+    from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
+    L = api.lib()
+    mesh = kuhn_cube(M, jitter=0.2)
+    Ng = mesh.num_node
+    wg0, dw0 = synthetic_fields(mesh)
+    wgold = wg0.copy()
+    wgold[3 * Ng:4 * Ng] = 0.0
+    dwgold = 0.1 * dw0
+    dwg = dwgold.copy()
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+
+    def new_solver(P, comm=None):
+        L.KrylovDestroy(P.ksp)
+        P.ksp = L.KrylovCreateGMRES(200, 1e-14, 1e-8, None)
+        L.KrylovSetVerbose(P.ksp, 0)
+        L.KrylovSetAggregateSize(P.ksp, 27)
+        L.KrylovSetPCType(P.ksp, api.PC_TWOLEVEL)      # (the mesh reaches the solver through SolveFlowSystem)
+        if comm is not None:
+            comm.install(P.ksp)
+
+    def stats(P):
+        st = L.KrylovGetStats(P.ksp).contents
+        return st.total_solves, st.total_converged, st.total_iterations
+
+    # ---- the whole mesh in this process ----
+    Pg = api.Problem(mesh, maxit=200, atol=0.0, rtol=1e-8)
+    new_solver(Pg)
+    g = [api.DeviceArray.from_numpy(v) for v in (wgold, dwgold, dwg)]
+    Fg, dxg = api.DeviceArray(6 * Ng), api.DeviceArray(6 * Ng)
+    ref = []
+    for k in range(its):
+        it, rn, ri = Pg.time_step(g[0], g[1], g[2], Fg, dxg, newton_maxit=2)
+        api.sync()
+        ref.append((it, rn, ri))
+    ref_state = (g[0].numpy(), g[1].numpy())
+    sg = stats(Pg)
+    assert sg[0] == sg[1] == 2 * its, sg
+    Pg.close()
+
+    # ---- the partition ----
+    lm, _, _, _, _ = dist_bench.distribute_problem(M, 0.2, rank, world, dist)
+    lm, alloc, P, plan, comm = dist_bench.setup_rank(lm, rank, world, device, dist, 200, True)
+    new_solver(P, comm)
+    n = P.N
+    vecs = [dist_bench.device_vector(alloc, torch, device, 6 * n, D.localize_vector(v, lm, Ng)) for v in (wgold, dwgold, dwg)]
+    F_t, F_p = dist_bench.device_vector(alloc, torch, device, 6 * n)
+    dx_t, dx_p = dist_bench.device_vector(alloc, torch, device, 6 * n)
+    Pp = dist_bench._Ptr
+    for k in range(its):
+        it, rn, ri = P.time_step(Pp(vecs[0][1]), Pp(vecs[1][1]), Pp(vecs[2][1]), Pp(F_p), Pp(dx_p), newton_maxit=2)
+        torch.cuda.synchronize()
+        it_o, rn_o, ri_o = ref[k]
+        assert it == it_o, (k, it, it_o)
+        assert np.allclose(ri, ri_o, rtol=1e-6, atol=1e-9 * ref[0][2].max()), (k, ri, ri_o)
+        assert np.allclose(rn, rn_o, rtol=1e-3, atol=1e-7 * ref[0][2].max()), (k, rn, rn_o)
+    sp_ = stats(P)
+    assert sp_[0] == sp_[1] == 2 * its, sp_
+    assert abs(sp_[2] - sg[2]) <= max(4, int(0.25 * sg[2])), (sp_, sg)       # total iterations within 25 %
+    for (t, _), r in zip(vecs[:2], ref_state):
+        loc = t.cpu().numpy()
+        exp = D.localize_vector(r, lm, Ng)
+        assert np.abs(loc - exp).max() <= 1e-6 * np.abs(r).max(), np.abs(loc - exp).max() / np.abs(r).max()
+    dist.barrier()
+    if rank == 0:
+        print("DIST_TRANSIENT_TWOLEVEL_OK", world, its, sp_[2], sg[2])
+    P.close()
+
+
 def run_gpu_twolevel(rank, world, M, its):
     """PC_TWOLEVEL on the element-partitioned matrix (aggregates per rank over owned nodes, replicated Galerkin coarse
     problem, rank-local DILU smoothing) against the same preconditioner on the whole mesh in one process: iteration count to
@@ -420,6 +498,7 @@ if __name__ == "__main__":
         import torch
         torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl" if mode == "gpu_rccl" else "gloo", rank=rank, world_size=world)
-    {"cpu": run_cpu, "gpu": run_gpu, "gpu_step": run_gpu_step, "gpu_rccl": run_gpu_rccl, "gpu_twolevel": run_gpu_twolevel}[mode](rank, world, M, its)
+    {"cpu": run_cpu, "gpu": run_gpu, "gpu_step": run_gpu_step, "gpu_rccl": run_gpu_rccl, "gpu_twolevel": run_gpu_twolevel,
+     "gpu_transient_twolevel": run_gpu_transient_twolevel}[mode](rank, world, M, its)
     dist.barrier()
     dist.destroy_process_group()

@@ -90,6 +90,14 @@ def test_distributed_twolevel_gpu_gloo(world, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_distributed_transient_twolevel_gpu_gloo(oracle_lib):
+    """BASELINE config 5 in small on 2 ranks: 3 time steps of 2 Newton iterations on the partitioned mesh
+    with PC_TWOLEVEL, every solve converged, Newton counts / residuals / final states equal to the one-process transient."""
+    out = _launch("gpu_transient_twolevel", 2, 14, 3)
+    assert "DIST_TRANSIENT_TWOLEVEL_OK" in out
+
+
+@pytest.mark.gpu
 def test_distributed_pipelined_gmres_gpu_gloo(oracle_lib):
     """KrylovSetPipelined (p(1)-GMRES: one reduction per step, overlapped with the next matvec through the auxiliary basis
     z = A M^-1 v) on a 2-way partition: residual history of the single-domain oracle at the loosened tolerance 1e-6 r0, same
