@@ -15,7 +15,8 @@
  * MatrixFS, and Ac^-1 is an inner KrylovSolve on it to rtol 0.1, so the outer solver has to be flexible (KrylovSolve
  * switches FGMRES on when it builds this PC).  While the coarse level has more than DFL_TL_COARSEST (262144) nodes its inner
  * solver is FGMRES preconditioned by another PCTwoLevel on the aggregate centroids (a K-cycle: a handful of inner
- * iterations per level, every level 1/agg_size of the one above); the last level is DILU-GMRES.  With a single coarse level
+ * iterations per level, every level 1/agg_size of the one above); the last level is DILU-GMRES (Jacobi-GMRES when it has
+ * <= 131072 nodes: see tl_build).  With a single coarse level
  * the inner Jacobi/DILU iteration count grows with the coarse grid and the 50M-tet case (232k aggregates) ran into its cap.
  * No post-smoothing: a second DILU sweep after the correction (z += S (r - A z)) stalls the 50M-tet solve at 1e-3 -- the
  * block-DILU iteration is not a convergent smoother for this stabilised (u,p) system on fine meshes, which is also why the
@@ -56,6 +57,8 @@ typedef struct PCTwoLevel {
     f64 *d_t, *d_rc, *d_xc;
     index_type inner_maxit;
     f64 inner_rtol;
+    b32 inner_rtol_given; /* set through PCTwoLevelSetInner: the per-solver default does not replace it */
+    b32 inner_jacobi;     /* last level solved by Jacobi-GMRES (small coarse levels) instead of DILU-GMRES */
     int64_t inner_iterations;
     const f64* xyz;              /* [N][3] host coordinates the aggregates are cut from */
     f64* xyz_owned;              /* coarse levels own theirs (aggregate centroids) */
@@ -358,8 +361,27 @@ static void tl_build(PCTwoLevel* d) {
         KrylovSetFlexible(d->cksp, TRUE);
         KrylovSetCheckInterval(d->cksp, 2);
     } else {
-        d->cksp->pc = PCCreateDILU(d->Ac);
-        KrylovSetCheckInterval(d->cksp, 4);
+        /* The last level's solver.  A coarse level of <= 131072 nodes is LATENCY-bound: a DILU application is 2 x 12 colour
+           launches of 8-10 us each (a chain of four dependent loads per launch) for 18 us of matvec, 340 us per inner
+           iteration against 70 us with the reference's Jacobi tree, which needs only twice the iterations (to rtol 0.05,
+           where the outer count is the same: 20 at 1.3M and 10M tets): 10M tets 116 -> 88 ms per solve, 1.3M tets 46 -> 27 ms.
+           Above that size DILU wins (50M tets, 232k aggregates: 713 against 782 ms).  DFL_TL_INNER_PC=jacobi|dilu forces
+           one; an inner tolerance set through PCTwoLevelSetInner / DFL_TL_INNER_RTOL is kept as given.
+           DFL_TL_INNER_CHECK = convergence test every k inner iterations (default 4). */
+        index_type jacobi_max = 131072;
+        if (getenv("DFL_TL_INNER_JACOBI_MAX")) jacobi_max = atoi(getenv("DFL_TL_INNER_JACOBI_MAX"));
+        b32 jacobi = Nc <= jacobi_max;
+        if (getenv("DFL_TL_INNER_PC")) jacobi = !strcmp(getenv("DFL_TL_INNER_PC"), "jacobi");
+        if (jacobi) {
+            d->cksp->pc = DflKrylovBuildPC(d->cksp, d->Ac);
+            /* 4 launches per inner iteration instead of 7 (the norm by Pythagoras: exact enough for a solve to rtol 0.05) */
+            if (!getenv("DFL_TL_INNER_FUSED") || atoi(getenv("DFL_TL_INNER_FUSED"))) KrylovSetFusedNorm(d->cksp, TRUE);
+            if (!d->inner_rtol_given && !getenv("DFL_TL_INNER_RTOL")) d->cksp->rtol = d->inner_rtol = 0.05;
+        } else {
+            d->cksp->pc = PCCreateDILU(d->Ac);
+        }
+        d->inner_jacobi = jacobi;
+        KrylovSetCheckInterval(d->cksp, getenv("DFL_TL_INNER_CHECK") ? atoi(getenv("DFL_TL_INNER_CHECK")) : 4);
     }
     d->Nc = Nc;
     d->Nc_local = Ncl;
@@ -475,6 +497,7 @@ void PCTwoLevelSetInner(PC* pc, index_type max_iter, f64 rtol) {
     PCTwoLevel* d = (PCTwoLevel*)pc->data;
     d->inner_maxit = max_iter;
     d->inner_rtol = rtol;
+    d->inner_rtol_given = TRUE;
     if (d->cksp) {
         d->cksp->max_iter = max_iter;
         d->cksp->rtol = rtol;

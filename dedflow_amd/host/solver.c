@@ -673,11 +673,12 @@ static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe) {
     b32 pend = FALSE;            /* a convergence check has been enqueued and not been looked at yet */
     b32 pend_first = FALSE;      /* ... and the first read of the solve travels with it */
     index_type final_check = -1; /* beta index whose value decides convergence at the end-of-solve synchronisation */
-    /* partitioned + fused norm + Jacobi tree on the (u,p) rows: update, Givens step and the next step's preconditioner
-       application in one launch (csrc/k_blas.hip, cgs_update_pc_kernel) */
+    /* fused norm + Jacobi tree on the (u,p) rows (partitioned runs of <= 500k owned nodes; the small last-level solver of
+       PC_TWOLEVEL, which is bound by launch latency): update, Givens step and the next step's preconditioner application in
+       one launch (csrc/k_blas.hip, cgs_update_pc_kernel) */
     const f64 *fj_d33 = NULL, *fj_d1 = NULL;
     index_type fj_N = 0, fj_rows = 0;
-    const b32 fuse_pc = dist && ex->fused_norm && !Zb && m + 2 <= 1024 && getenv("DFL_NO_FUSED_UPDATE_PC") == NULL &&
+    const b32 fuse_pc = ex->fused_norm && !Zb && m + 2 <= 1024 && getenv("DFL_NO_FUSED_UPDATE_PC") == NULL &&
                         jacobi_tree_data(pc, &fj_d33, &fj_d1, &fj_N, &fj_rows) && na == 4 * fj_N && fj_rows > 0 &&
                         fj_rows <= 500000; /* measured: 38 us against 31 + 7 + 6 us for the three kernels at 227k owned nodes, but
                                               274 us against 192 + 46 + 10 us at 1.73M (the node-per-thread mapping streams the
@@ -754,17 +755,17 @@ static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe) {
             /* 3. classical Gram-Schmidt */
             if (fuse_pc) {
                 DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 2, Q, na, QCOL(iter + 1), ex->hraw, ex->work, s));
-                ex->comm.allreduce_sum(ex->comm.ctx, ex->hraw, iter + 2);
+                if (dist) ex->comm.allreduce_sum(ex->comm.ctx, ex->hraw, iter + 2);
                 DFL_TIMED(DFL_TAG_CGS_UPDATE,
                           dfl_cgs_update_pc_givens(fj_rows, fj_N, iter + 1, Q, na, ex->hraw, QCOL(iter + 1), fj_d33, fj_d1, tmp, iter, H, ldh,
                                                    ex->gv, ex->beta, res_hist, ex->nrm + iter + 1, ex->d_flag, s));
                 z_ready = TRUE;
                 goto arnoldi_step_done;
             }
-            if (dist && ex->fused_norm) {
+            if (ex->fused_norm) {
                 /* w itself is column iter+1 of Q: one extra "column" of the dots gives w.w, one all-reduce carries h and w.w */
                 DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 2, Q, na, QCOL(iter + 1), HCOL(iter), ex->work, s));
-                ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 2);
+                if (dist) ex->comm.allreduce_sum(ex->comm.ctx, HCOL(iter), iter + 2);
                 DFL_TIMED(DFL_TAG_CGS_UPDATE, dfl_cgs_update(na, iter + 1, Q, na, HCOL(iter), QCOL(iter + 1), NULL, 0, ex->work, s));
                 dfl_gmres_givens_pythagoras(iter, ex->nrm + iter + 1, H, ldh, ex->gv, ex->beta, res_hist, ex->d_flag, s);
                 goto arnoldi_step_done;
@@ -846,7 +847,7 @@ static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe) {
     if (nh) HIPGUARD(hipMemcpyAsync(ex->stats.res_hist, ex->res_hist, sizeof(f64) * (size_t)nh, D2H, s));
     ex->stats.fused_norm_cancelled = FALSE;
     int flag = 0;
-    if (dist && ex->fused_norm) {
+    if (ex->fused_norm) {
         HIPGUARD(hipMemcpyAsync(&flag, ex->d_flag, sizeof flag, D2H, s));
         HIPGUARD(hipMemsetAsync(ex->d_flag, 0, sizeof(int), s));
     }

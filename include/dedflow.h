@@ -436,9 +436,11 @@ void KrylovSetCheckInterval(Krylov* krylov, index_type k);
 void KrylovSetVerbose(Krylov* krylov, b32 verbose);
 void KrylovSetPCType(Krylov* krylov, PCType type); /* PC_DECOMPOSITION (default, reference tree), PC_ILU0 or PC_TWOLEVEL */
 PC* KrylovGetPC(const Krylov* krylov);
-/* partitioned runs only, off by default: the norm of the orthogonalised vector from w.w - sum h_j^2, so that an Arnoldi
- * step needs ONE all-reduce (h and w.w together) instead of two; rounding differs from the explicit norm and heavy
- * cancellation raises KrylovStats.fused_norm_cancelled */
+/* off by default: the norm of the orthogonalised vector from w.w - sum h_j^2, so that a partitioned Arnoldi step needs ONE
+ * all-reduce (h and w.w together) instead of two and, with the Jacobi tree on <= 500k rows, ONE launch for update + Givens
+ * step + next preconditioner application (7 -> 4 launches per step; since round 3 also without a communicator -- the
+ * last-level solver of PC_TWOLEVEL uses it); rounding differs from the explicit norm and heavy cancellation raises
+ * KrylovStats.fused_norm_cancelled */
 void KrylovSetFusedNorm(Krylov* krylov, b32 on);
 /* p(1)-pipelined GMRES (host/solver.c, gmres_pipelined; build-defined, off by default): ONE reduction per Arnoldi step -- the CGS
  * coefficients and w.w together, the norm from the Pythagorean identity -- overlapped with the matvec of the NEXT step through

@@ -47,7 +47,7 @@ for w in which:
     busy += cur_end - cur_s
     wall = t1 - t0
     print("step %d: wall %.1f us, union busy %.1f us, idle %.1f us, kernels %d" % (w, wall / 1e3, busy / 1e3, (wall - busy) / 1e3, len(seg)))
-    for k, v in sorted(d.items(), key=lambda kv: -kv[1][1])[:14]:
+    for k, v in sorted(d.items(), key=lambda kv: -kv[1][1])[:24]:
         print("   %-44s stream %-3s queue %-3s %4d %8.1f us  avg %6.1f" % (k[0], k[1], k[2], v[0], v[1] / 1e3, v[1] / v[0] / 1e3))
-    for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:6]:
+    for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:10]:
         print("   gap %8.1f us (%3d x %5.1f)  %s -> %s" % (v[1] / 1e3, v[0], v[1] / v[0] / 1e3, k[0], k[1]))
