@@ -124,6 +124,21 @@ __global__ __launch_bounds__(BLK) void dilu_sweep_kernel(I slot0, I nrows_c, con
     double acc0 = 0.0, acc1 = 0.0;
     int q = eptr[slot];
     const int qe = eptr[slot + 1];
+    // (a triangle of a nodal row holds ~7 neighbours: four block lines in flight first, then the tail in twos and ones; the
+    // association of the sums is that of the two-at-a-time loop: entries q, q+2, ... into acc0, the others into acc1)
+    for (; q + 4 <= qe; q += 4) {
+        const int k0 = enz[q], k1 = enz[q + 1], k2 = enz[q + 2], k3 = enz[q + 3];
+        const int c0 = ecol[q], c1 = ecol[q + 1], c2 = ecol[q + 2], c3 = ecol[q + 3];
+        const d2v a0 = v2[(long long)k0 * 8], a1 = v2[(long long)k1 * 8], a2 = v2[(long long)k2 * 8], a3 = v2[(long long)k3 * 8];
+        const double x0a = z[hi ? 3LL * c0 + 2 : 3LL * c0], x0b = z[hi ? N3 + c0 : 3LL * c0 + 1];
+        const double x1a = z[hi ? 3LL * c1 + 2 : 3LL * c1], x1b = z[hi ? N3 + c1 : 3LL * c1 + 1];
+        const double x2a = z[hi ? 3LL * c2 + 2 : 3LL * c2], x2b = z[hi ? N3 + c2 : 3LL * c2 + 1];
+        const double x3a = z[hi ? 3LL * c3 + 2 : 3LL * c3], x3b = z[hi ? N3 + c3 : 3LL * c3 + 1];
+        acc0 += a0.x * x0a + a0.y * x0b;
+        acc1 += a1.x * x1a + a1.y * x1b;
+        acc0 += a2.x * x2a + a2.y * x2b;
+        acc1 += a3.x * x3a + a3.y * x3b;
+    }
     for (; q + 2 <= qe; q += 2) {
         const int k0 = enz[q], k1 = enz[q + 1], c0 = ecol[q], c1 = ecol[q + 1];
         const d2v a0 = v2[(long long)k0 * 8], a1 = v2[(long long)k1 * 8];

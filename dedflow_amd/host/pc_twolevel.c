@@ -421,10 +421,9 @@ static void tl_apply(PC* pc, value_type* r, value_type* z) {
     const index_type N = d->N, Nc = d->Nc, n = d->n_active > 0 ? d->n_active : d->n;
     PCDILUSetActiveLength(d->smoother, n);
     PCApply(d->smoother, r, z);                 /* z = S r (copies the phi / T tail when n > 4N) */
-    dfl_dcopy(4 * N, r, d->d_t, s);
     if (d->dist) d->comm.halo_exchange(d->comm.ctx, z); /* the owned rows of A read ghost entries of z */
-    MatrixAMVPBY(A, -1.0, z, 1.0, d->d_t);      /* t = r - A z on the (u,p) part (owned rows) */
-    dfl_amg_restrict(Nc, d->d_aoff, d->d_anode, N, d->d_t, d->d_rc, s);
+    MatrixMatVec(A, z, d->d_t);                 /* t = A z on the (u,p) part (owned rows); the restriction forms r - t */
+    dfl_amg_restrict_diff(Nc, d->d_aoff, d->d_anode, N, r, d->d_t, d->d_rc, s);
     /* partitioned: rc is zero outside this rank's aggregates; the sum over ranks is the whole coarse residual, on every rank */
     if (d->dist) dist_sum_f64(&d->comm, d->d_rc, 4 * (int64_t)Nc);
     HIPGUARD(hipMemsetAsync(d->d_xc, 0, (size_t)Nc * 6 * sizeof(f64), s));

@@ -407,6 +407,9 @@ void dfl_amg_galerkin(dfl_index nnzc, const dfl_index* off, const dfl_index* idx
                       void* stream);
 void dfl_amg_restrict(dfl_index Nc, const dfl_index* aoff, const dfl_index* anode, dfl_index N, const dfl_value* r, dfl_value* rc,
                       void* stream);
+/* the same of r - sub (the residual r - A z with sub = A z from a plain matvec) */
+void dfl_amg_restrict_diff(dfl_index Nc, const dfl_index* aoff, const dfl_index* anode, dfl_index N, const dfl_value* r,
+                           const dfl_value* sub, dfl_value* rc, void* stream);
 void dfl_amg_prolong_add(dfl_index N, const dfl_index* agg, dfl_index Nc, const dfl_value* xc, dfl_value* z, void* stream);
 /* the same for rows [0, nrows) of N (partitioned runs: the owned nodes come first) */
 void dfl_amg_prolong_add_rows(dfl_index nrows, dfl_index N, const dfl_index* agg, dfl_index Nc, const dfl_value* xc, dfl_value* z,
