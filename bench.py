@@ -170,6 +170,11 @@ def main():
     if world > 1 and args.gpus != world:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
+    # stdout carries the ONE JSON line and nothing else: whatever a library prints there meanwhile (the RCCL version banner,
+    # gloo's connection notes) is sent to stderr; the line itself goes to the saved descriptor at the end
+    sys.stdout.flush()
+    args._stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     if world > 1 or os.environ.get("DFL_FORCE_DIST") == "1":  # DFL_FORCE_DIST: rehearse the N>1 leg on one rank
         from dedflow_amd import dist_bench
         return dist_bench.run(args, rank, world, local_rank)
@@ -464,7 +469,8 @@ def main():
             its * ab["spmv"] + sum(ab["cgs"]) + (its + 1) * ab["pc_apply"] + 8.0 * 4 * N * (its + 2)),
         "setup_s": t_setup, "gmres_residual_drop": float(hist[-1] / r0) if len(hist) else None,
     }
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(args._stdout_fd, (json.dumps(out) + "\n").encode())
     P.close()
 
 

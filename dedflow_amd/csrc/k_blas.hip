@@ -514,6 +514,19 @@ __global__ __launch_bounds__(BLK) void gmres_trsv_kernel(I m, const T* __restric
 
 __global__ void sqrt_kernel(T* v) { v[0] = sqrt(v[0]); }
 
+// one wave that stays resident for about `us` microseconds of the constant 100 MHz clock (bounded by an iteration count as
+// well, so that it ends whatever the clock does): lets a host routine find out whether two streams run CONCURRENTLY
+__global__ void spin_kernel(int us, int* sink) {
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long ticks = (unsigned long long)us * 100ull;
+    int it = 0;
+    while (wall_clock64() - t0 < ticks && it < (1 << 22)) {
+        __builtin_amdgcn_s_sleep(32);
+        ++it;
+    }
+    if (sink && it < 0) *sink = it;
+}
+
 __global__ void residual_update_kernel(T* beta, T* gv) {
     double b0 = beta[0];
     beta[1] = -gv[1] * b0;
@@ -761,6 +774,12 @@ void dfl_cgs_update_givens(I n, I ncol, const T* Q, int64_t ldq, const T* d_h, T
     int g = ceil_div(n, UROWS);
     CGS_UPDATE_LAUNCH(n, ncol, Q, ldq, d_h, w, work);
     norm_givens_kernel<<<1, BLK, 0, S(stream)>>>(g, work, d_nrm, iter, d_H, ldh, d_gv, d_beta, d_res_hist);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_spin_us(int us, void* stream) {
+    if (us <= 0) return;
+    if (us > 20000) us = 20000;
+    spin_kernel<<<1, 64, 0, S(stream)>>>(us, nullptr);
     DFL_LAUNCH_CHECK();
 }
 void dfl_dsqrt_dev(T* d_val, void* stream) {

@@ -132,6 +132,21 @@ def run(args, rank, world, local_rank):
         x_t.zero_()
         return P.solve(_Ptr(x_p), _Ptr(F_p))
 
+    # Krylov work-space placement, as in the one-GPU line (bench.py --placement): the explicit calibration
+    # before the warm-up, every rank for itself on its own GPU -- it contains no collective, and the library skips it below
+    # 2^20 unknowns per rank (the 8-way share of the 10M-tet mesh).  Not when several ranks share one card (rehearsals).
+    placement = getattr(args, "placement", "default")
+    t_cal = 0.0
+    if placement == "calibrate" and "DFL_FORCE_DEVICE" not in os.environ:
+        L.DflKrylovCalibratePlacement.argtypes = [C.c_void_p, C.POINTER(api.Matrix), C.c_int64]
+        L.DflKrylovCalibratePlacement.restype = None
+        P.assemble_system(_Ptr(wg_p), _Ptr(dwg_p), None, want_J=True)     # (real values in the matrix the loop is timed on)
+        tc = time.perf_counter()
+        L.DflKrylovCalibratePlacement(P.ksp, P.J, int(getattr(args, "placement_cap_gb", 0.0) * 2 ** 30))
+        torch.cuda.synchronize()
+        t_cal = time.perf_counter() - tc
+    dist.barrier()
+
     # one all-reduce per Arnoldi step (h and w.w together, KrylovSetFusedNorm) unless DFL_FUSED_NORM=0; the warm-up steps
     # double as the check: if any rank saw heavy cancellation in the Pythagorean norm, fall back to the explicit norm
     fused = os.environ.get("DFL_FUSED_NORM", "1") != "0"
@@ -237,7 +252,9 @@ def run(args, rank, world, local_rank):
                                    f"Jacobi-PC GMRES x{its} iterations; RCB element partition over {world} ranks, "
                                    f"one halo layer assembled redundantly, halo exchange + all-reduce on {backend}; mesh generated and "
                                    f"partitioned once on rank 0, local pieces scattered",
-                       "gmres_its": its, "parallelism": f"dd{world}"},
+                       "gmres_its": its, "parallelism": f"dd{world}",
+                       "placement": (f"explicit DflKrylovCalibratePlacement per rank before the warm-up ({t_cal:.1f} s on rank 0)"
+                                     if t_cal > 0 else "library default (bounded pick inside the first solve)")},
             "per_rank": {"local_tets": [r[0] for r in per_rank], "owned_nodes": [r[1] for r in per_rank],
                          "halo_send_bytes": [r[2] for r in per_rank], "colors": [r[3] for r in per_rank]},
             "redundant_assembly_fraction": sum(r[0] for r in per_rank) / Tg - 1.0,
@@ -246,6 +263,11 @@ def run(args, rank, world, local_rank):
             "roofline": roofline, "cpu_baseline": None, "setup_s": t_setup, "solve_to_rtol": to_rtol,
             "gmres_residual_drop": float(hist[-1] / r0) if len(hist) else None,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        fd = getattr(args, "_stdout_fd", None)   # bench.py keeps stdout for this one line (library chatter goes to stderr)
+        if fd is None:
+            print(json.dumps(out))
+        else:
+            os.write(fd, (json.dumps(out) + "\n").encode())
     dist.barrier()
     dist.destroy_process_group()

@@ -144,6 +144,59 @@ static void rccl_halo_end(void* ctx, f64* d_x) {
 static hipStream_t rccl_halo_stream(void* ctx) { return ((DflRcclComm*)ctx)->side; }
 
 /* collective over all ranks: every rank passes the same 128-byte id */
+/* A stream that really runs BESIDE `main_stream`.  HIP maps streams onto a handful of hardware queues round-robin; a side
+ * stream that lands on the main stream's own queue runs its kernels AFTER the main stream's instead of beside them (rank 0 of
+ * the 8-way partition: boundary rows behind the interior rows, both event hops 10 us instead of 6), and which queue a new
+ * stream gets depends on how many streams the process made before (torch, RCCL).  A stream of the HIGHEST priority always gets
+ * a queue of its own -- and was worse: in some processes every kernel of the normal-priority library stream then ran with random
+ * delays of 0-100 us for as long as that stream lived (first problem of a process: 59 instead of 46 ms per 10M-tet step, 17.6
+ * instead of 7.2 ms for the 8-way share; tools/probe_rank_local.py with DFL_HALO_STREAM_PRIORITY=high).  So: default priority,
+ * and the candidate is PROBED -- a 300-us resident wave on the main stream, an empty launch on the candidate: if the
+ * candidate's launch ends first the two overlap.  Up to 6 candidates; the rejected ones are destroyed afterwards (destroying
+ * one at once would hand its queue to the next).  DFL_HALO_STREAM_PRIORITY=high|default skips the probe. */
+hipStream_t DflPickConcurrentStream(hipStream_t main_stream) {
+    hipStream_t pick = NULL;
+    const char* force = getenv("DFL_HALO_STREAM_PRIORITY");
+    if (force && !strcmp(force, "high")) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        HIPGUARD(hipStreamCreateWithPriority(&pick, hipStreamNonBlocking, hi));
+        return pick;
+    }
+    if (force && !strcmp(force, "default")) {
+        HIPGUARD(hipStreamCreateWithFlags(&pick, hipStreamNonBlocking));
+        return pick;
+    }
+    enum { MAXC = 6 };
+    hipStream_t cand[MAXC];
+    int nc = 0;
+    hipEvent_t em, es;
+    HIPGUARD(hipEventCreate(&em));
+    HIPGUARD(hipEventCreate(&es));
+    HIPGUARD(hipStreamSynchronize(main_stream));
+    for (; nc < MAXC && !pick; ++nc) {
+        HIPGUARD(hipStreamCreateWithFlags(&cand[nc], hipStreamNonBlocking));
+        for (int rep = 0; rep < 2 && !pick; ++rep) { /* (a first launch on a new stream may pay set-up time: two tries) */
+            dfl_spin_us(300, main_stream);
+            HIPGUARD(hipEventRecord(em, main_stream));
+            dfl_spin_us(1, cand[nc]);
+            HIPGUARD(hipEventRecord(es, cand[nc]));
+            HIPGUARD(hipEventSynchronize(em));
+            HIPGUARD(hipEventSynchronize(es));
+            float ms = 0.f; /* from the end of the candidate's launch to the end of the main stream's wave */
+            HIPGUARD(hipEventElapsedTime(&ms, es, em));
+            if (ms > 0.1f) pick = cand[nc]; /* the candidate was done >= 100 us before the 300-us wave: they overlapped */
+        }
+    }
+    if (!pick) pick = cand[0]; /* every candidate shares the main stream's queue (GPU_MAX_HW_QUEUES=1?): correct, only slower */
+    for (int k = 0; k < nc; ++k)
+        if (cand[k] != pick) HIPGUARD(hipStreamDestroy(cand[k]));
+    HIPGUARD(hipEventDestroy(em));
+    HIPGUARD(hipEventDestroy(es));
+    if (getenv("DFL_WS_VERBOSE")) fprintf(stderr, "[comm] halo stream: candidate %d of %d runs beside the library stream\n", nc, MAXC);
+    return pick;
+}
+
 DflRcclComm* DflRcclCommCreate(const char* id128, int rank, int world) {
     if (!R.handle) {
         fprintf(stderr, "DflRcclCommCreate: call DflRcclLoad first\n");
@@ -167,16 +220,7 @@ DflRcclComm* DflRcclCommCreate(const char* id128, int rank, int world) {
     c->recv_count = (index_type*)CdamMallocHost(SIZE_OF(index_type) * world);
     memset(c->send_count, 0, sizeof(index_type) * (size_t)world);
     memset(c->recv_count, 0, sizeof(index_type) * (size_t)world);
-    {   /* the halo stream gets the HIGHEST priority: (1) halo traffic and the boundary rows behind it are the latency-critical
-           part of a matvec and should not queue behind the interior rows' workgroups; (2) streams of the default priority
-           share a handful of hardware queues with the library (null) stream -- when the side stream landed on the library
-           stream's own queue, its kernels ran AFTER the interior rows instead of beside them and both hops cost 10 us
-           instead of 6 (rocprofv3 trace of rank 0 vs rank 4 of the 8-way partition, profiles/r03_rank_local_trace.txt) */
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
-        if (getenv("DFL_HALO_STREAM_DEFAULT_PRIORITY")) hi = 0;
-        HIPGUARD(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
-    }
+    c->side = DflPickConcurrentStream(DflStream());
     /* both events order work of ONE device across two of its streams (x complete -> pack; unpack -> boundary rows): no
        system-scope fence needed -- the peers' data arrives through RCCL's own kernels -- and without it the record / wait
        pair costs less idle time on the library stream (DFL_EVENT_SYSTEM_FENCE=1 restores the default) */

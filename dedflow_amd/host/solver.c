@@ -421,7 +421,7 @@ static void gmres_pipelined(Matrix* A, f64* x, f64* b, Krylov* ksp) {
     }
     const b32 own_stream = dist && ex->comm.halo_stream && ex->comm.halo_stream(ex->comm.ctx) != NULL;
     if (own_stream && !ex->red_stream) {
-        HIPGUARD(hipStreamCreateWithFlags(&ex->red_stream, hipStreamNonBlocking));
+        ex->red_stream = DflPickConcurrentStream(s); /* a stream that really overlaps the library stream (host/comm_rccl.c) */
         HIPGUARD(hipEventCreateWithFlags(&ex->ev_w, hipEventDisableTiming));
         HIPGUARD(hipEventCreateWithFlags(&ex->ev_h, hipEventDisableTiming));
     }

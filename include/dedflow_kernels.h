@@ -56,6 +56,9 @@ void dfl_scatter_idx(dfl_index n, const dfl_index* idx, const dfl_value* in, dfl
 dfl_index dfl_reduce_work_size(void);
 void dfl_ddot(dfl_index n, const dfl_value* x, const dfl_value* y, dfl_value* d_out, dfl_value* work, void* stream);
 void dfl_dnrm2(dfl_index n, const dfl_value* x, dfl_value* d_out, dfl_value* work, void* stream);
+/* one resident wave for about `us` microseconds (<= 20000; bounded whatever the clock does): a probe for whether two streams
+ * of this process run concurrently (host/comm_rccl.c picks its halo stream with it) */
+void dfl_spin_us(int us, void* stream);
 /* x *= 1 / *d_scale  (cublasDscal with the reciprocal of a device-resident norm, krylov.c:130-131,235-237) */
 void dfl_dscal_inv_dev(dfl_index n, const dfl_value* d_scale, dfl_value* x, void* stream);
 

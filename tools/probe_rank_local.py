@@ -5,6 +5,10 @@ Launch: python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0
 import sys, os, time, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("PROBE_EARLY_INIT") == "1":   # reserve the library's device pool BEFORE torch / RCCL allocate anything
+    from dedflow_amd import api as _api
+    _api.hip().hipSetDevice(0)
+    _api.lib().Init(0, None)
 import torch, torch.distributed as dist
 from dedflow_amd import api, dist as D, dist_bench
 from dedflow_amd.meshgen import kuhn_cube, synthetic_fields
@@ -21,7 +25,7 @@ mesh = kuhn_cube(M, jitter=0.2)
 wg, dwg = synthetic_fields(mesh)
 epart = D.partition_rcb(mesh, parts)
 owner = D.node_owner(mesh, epart, parts)
-for r in (0, parts // 2):
+for r in ((0,) * int(os.environ["PROBE_REPEAT"]) if os.environ.get("PROBE_REPEAT") else (0, parts // 2)):
     lm = D.build_local(mesh, epart, owner, r, parts)
     P = api.Problem(lm.mesh, maxit=its, atol=0.0, rtol=0.0, quiet=True)
     L = api.lib()
@@ -50,6 +54,13 @@ for r in (0, parts // 2):
         P.assemble_system(Pp(wg_p), Pp(dwg_p), None, want_J=True)
         F_t[3 * no:3 * n].zero_(); F_t[3 * n + no:4 * n].zero_(); x_t.zero_()
         return P.solve(Pp(x_p), Pp(F_p))
+    if os.environ.get("PROBE_SLEEP"):
+        torch.cuda.synchronize(); time.sleep(float(os.environ["PROBE_SLEEP"]))
+    if os.environ.get("PROBE_WAIT") == "1":     # the driver's background wipe of what the set-up freed
+        L.DflWaitDeviceMemoryQuiet.restype = C.c_double
+        L.DflWaitDeviceMemoryQuiet.argtypes = [C.c_double]
+        torch.cuda.synchronize()
+        print("waited %.2f s for the device memory to be quiet" % L.DflWaitDeviceMemoryQuiet(30.0))
     for _ in range(3): step()
     K = 10
     batches = []
@@ -58,6 +69,18 @@ for r in (0, parts // 2):
         for _ in range(K): step()
         torch.cuda.synchronize(); batches.append(1e3 * (time.perf_counter() - t0) / K)
     ms = float(np.median(batches))
+    if os.environ.get("PROBE_TAGS") == "1":      # in-library event timing per kernel class over 5 more steps (as bench.py does)
+        L.DflProfileEnable.argtypes = [C.c_int]
+        L.DflProfileCollect.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.DflProfileCollect.restype = C.c_int
+        L.DflProfileEnable(1)
+        for _ in range(5): step()
+        torch.cuda.synchronize()
+        for name, tag in (("spmv", 0), ("cgs_dots", 1), ("cgs_update", 2), ("pc_apply", 3), ("asm_lhs", 4), ("asm_rhs", 5)):
+            tot, mn = C.c_double(), C.c_double()
+            cnt = L.DflProfileCollect(tag, C.byref(tot), C.byref(mn))
+            if cnt: print("   %-10s n=%4d avg %.4f ms  min %.4f ms" % (name, cnt, tot.value / cnt, mn.value))
+        L.DflProfileEnable(0)
     print("rank %d of %d: %d local tets (%d owned nodes, %d interior), %d collectives/step on a 1-rank communicator: %.2f ms per step"
           % (r, parts, P.T, no, lm.n_interior, (comm.n_allreduce + comm.n_halo) // (5 * K + 3), ms) +
           " (batches %s)" % ", ".join("%.2f" % b for b in batches), flush=True)
