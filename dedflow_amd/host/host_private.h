@@ -160,7 +160,4 @@ int DflSlotPatchLimitCheck(int64_t num_positions, int64_t num_tets, int64_t num_
                            size_t why_len);
 void DflSlotPatchSetTestLimits(int positions, int tets);
 
-/* host/comm_rccl.c: a non-blocking stream probed to run concurrently with `main_stream` (not on its hardware queue) */
-hipStream_t DflPickConcurrentStream(hipStream_t main_stream);
-
 #endif

@@ -449,6 +449,12 @@ void KrylovSetFusedNorm(Krylov* krylov, b32 on);
  * residual history (~1e-8 r0 instead of 1e-10; heavy cancellation raises KrylovStats.fused_norm_cancelled).  Ignored with
  * FGMRES / PC_TWOLEVEL and with restarts. */
 void KrylovSetPipelined(Krylov* krylov, b32 on);
+/* A non-blocking stream (default priority) that was PROBED to run concurrently with `main_stream`: HIP maps streams onto a few
+ * hardware queues round-robin, and a side stream on the main stream's own queue runs behind it instead of beside it; a
+ * highest-priority stream avoids that but was seen to delay every kernel of the normal-priority stream (host/comm_rccl.c).
+ * What the RCCL communicator uses for its halo exchange; a host that fills DflComm.halo_stream itself should create its stream
+ * with this.  The caller destroys it with hipStreamDestroy. */
+hipStream_t DflPickConcurrentStream(hipStream_t main_stream);
 /* GMRES(m): restart after m basis columns (x updated, true residual recomputed); m <= 0 or m >= max_iter (default) = the
  * reference's full GMRES.  Keeps the basis at m+1 vectors for long solves (config 5: 50M tets, PC_ILU0). */
 void KrylovSetRestart(Krylov* krylov, index_type m);
