@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 t0 = int(rows[0]["Start_Timestamp"])
 steps = [i for i, r in enumerate(rows) if "tet_lhs_slot" in r["Kernel_Name"]]
-names = {"spmv": "bcsr_spmv", "J": "tet_lhs_slot", "F": "tet_rhs_lane", "dots": "cgs_dots_stage1", "update": "cgs_update_kernel<true>", "pc": "pc_apply_kernel"}
+names = {"spmv": "bcsr_spmv", "J": "tet_lhs_slot", "F": "tet_rhs_lane", "dots": "cgs_dots_stage1", "update": "cgs_update_kernel<true", "pc": "pc_apply_kernel"}
 print("step   t[s]   " + "  ".join("%-14s" % k for k in names))
 for si, i in enumerate(steps):
     j = steps[si + 1] if si + 1 < len(steps) else len(rows)
