@@ -664,3 +664,35 @@ def test_array_blas_wrappers_and_field_vs_numpy(api, tmp_path):
     assert np.array_equal(api.d2h(g.contents.device.contents.data, m, np.float64), src)   # Load refreshes the device copy
     L.FieldDestroy(f); L.FieldDestroy(g)
     P.close()
+
+
+def test_pick_concurrent_stream_overlaps_the_library_stream(api):
+    """DflPickConcurrentStream (host/comm_rccl.c): the stream the halo exchange / boundary rows run on must really run BESIDE
+    the library stream -- a 2-ms resident wave on the library stream (dfl_spin_us, bounded) must not delay an empty launch on the
+    picked stream.  Also: the spin kernel ends by itself (its bound), in about the time asked for."""
+    import time
+    L, H = api.lib(), api.hip()
+    L.Init(0, None)
+    L.DflPickConcurrentStream.restype, L.DflPickConcurrentStream.argtypes = vp, [vp]
+    L.dfl_spin_us.argtypes = [C.c_int, vp]
+    H.hipStreamSynchronize.argtypes = [vp]
+    H.hipStreamDestroy.argtypes = [vp]
+    main = L.DflStream()
+    side = L.DflPickConcurrentStream(main)
+    assert side and side != main
+    api.sync()
+    t0 = time.perf_counter()
+    L.dfl_spin_us(2000, main)
+    H.hipStreamSynchronize(C.c_void_p(main))
+    dt = time.perf_counter() - t0
+    assert 1.5e-3 < dt < 50e-3, dt                      # ~2 ms, and it ended
+    # 20-ms wave on the library stream, then an empty launch on the side stream: the latter returns long before the former
+    L.dfl_spin_us(20000, main)
+    t0 = time.perf_counter()
+    L.dfl_spin_us(1, C.c_void_p(side))
+    H.hipStreamSynchronize(C.c_void_p(side))
+    t_side = time.perf_counter() - t0
+    H.hipStreamSynchronize(C.c_void_p(main))
+    t_main = time.perf_counter() - t0
+    assert t_side < 0.5 * t_main and t_main > 10e-3, (t_side, t_main)
+    assert H.hipStreamDestroy(C.c_void_p(side)) == 0
