@@ -106,10 +106,12 @@ __global__ __launch_bounds__(BLK) void dilu_setup_kernel(I nrows_c, const I* __r
 //                                   BWD: z_i -= E_i^-1 sum_{color(j)>color(i)} A_ij z_j
 // The L / U neighbours of every row are precomputed lists (eptr over the color-ordered row slots, enz = nodal nonzero,
 // ecol = column node), so the loop carries no color lookup and no predicate and issues two independent block loads per trip.
-template <bool FWD>
+// VT = float: the off-diagonal blocks come from the single-precision copy PC_TWOLEVEL keeps for its smoother (E^-1 and all
+// sums stay double)
+template <bool FWD, typename VT = T>
 __global__ __launch_bounds__(BLK) void dilu_sweep_kernel(I slot0, I nrows_c, const I* __restrict__ rows, I N,
                                                         const I* __restrict__ eptr, const I* __restrict__ enz,
-                                                        const I* __restrict__ ecol, const T* __restrict__ val,
+                                                        const I* __restrict__ ecol, const VT* __restrict__ val,
                                                         const T* __restrict__ Einv, const T* __restrict__ r, T* __restrict__ z) {
     const long long gid = (long long)blockIdx.x * BLK + threadIdx.x;
     const long long lslot = gid >> 3;
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(BLK) void dilu_sweep_kernel(I slot0, I nrows_c, con
     const long long N3 = 3LL * N;
     const int br = l >> 1;
     const bool hi = (l & 1);
-    const d2v* __restrict__ v2 = reinterpret_cast<const d2v*>(val) + l;
+    typedef VT v2t __attribute__((ext_vector_type(2)));
+    const v2t* __restrict__ v2 = reinterpret_cast<const v2t*>(val) + l;
     double acc0 = 0.0, acc1 = 0.0;
     int q = eptr[slot];
     const int qe = eptr[slot + 1];
@@ -129,28 +132,28 @@ __global__ __launch_bounds__(BLK) void dilu_sweep_kernel(I slot0, I nrows_c, con
     for (; q + 4 <= qe; q += 4) {
         const int k0 = enz[q], k1 = enz[q + 1], k2 = enz[q + 2], k3 = enz[q + 3];
         const int c0 = ecol[q], c1 = ecol[q + 1], c2 = ecol[q + 2], c3 = ecol[q + 3];
-        const d2v a0 = v2[(long long)k0 * 8], a1 = v2[(long long)k1 * 8], a2 = v2[(long long)k2 * 8], a3 = v2[(long long)k3 * 8];
+        const v2t a0 = v2[(long long)k0 * 8], a1 = v2[(long long)k1 * 8], a2 = v2[(long long)k2 * 8], a3 = v2[(long long)k3 * 8];
         const double x0a = z[hi ? 3LL * c0 + 2 : 3LL * c0], x0b = z[hi ? N3 + c0 : 3LL * c0 + 1];
         const double x1a = z[hi ? 3LL * c1 + 2 : 3LL * c1], x1b = z[hi ? N3 + c1 : 3LL * c1 + 1];
         const double x2a = z[hi ? 3LL * c2 + 2 : 3LL * c2], x2b = z[hi ? N3 + c2 : 3LL * c2 + 1];
         const double x3a = z[hi ? 3LL * c3 + 2 : 3LL * c3], x3b = z[hi ? N3 + c3 : 3LL * c3 + 1];
-        acc0 += a0.x * x0a + a0.y * x0b;
-        acc1 += a1.x * x1a + a1.y * x1b;
-        acc0 += a2.x * x2a + a2.y * x2b;
-        acc1 += a3.x * x3a + a3.y * x3b;
+        acc0 += (double)a0.x * x0a + (double)a0.y * x0b;
+        acc1 += (double)a1.x * x1a + (double)a1.y * x1b;
+        acc0 += (double)a2.x * x2a + (double)a2.y * x2b;
+        acc1 += (double)a3.x * x3a + (double)a3.y * x3b;
     }
     for (; q + 2 <= qe; q += 2) {
         const int k0 = enz[q], k1 = enz[q + 1], c0 = ecol[q], c1 = ecol[q + 1];
-        const d2v a0 = v2[(long long)k0 * 8], a1 = v2[(long long)k1 * 8];
+        const v2t a0 = v2[(long long)k0 * 8], a1 = v2[(long long)k1 * 8];
         const double x0a = z[hi ? 3LL * c0 + 2 : 3LL * c0], x0b = z[hi ? N3 + c0 : 3LL * c0 + 1];
         const double x1a = z[hi ? 3LL * c1 + 2 : 3LL * c1], x1b = z[hi ? N3 + c1 : 3LL * c1 + 1];
-        acc0 += a0.x * x0a + a0.y * x0b;
-        acc1 += a1.x * x1a + a1.y * x1b;
+        acc0 += (double)a0.x * x0a + (double)a0.y * x0b;
+        acc1 += (double)a1.x * x1a + (double)a1.y * x1b;
     }
     if (q < qe) {
         const int k0 = enz[q], c0 = ecol[q];
-        const d2v a0 = v2[(long long)k0 * 8];
-        acc0 += a0.x * z[hi ? 3LL * c0 + 2 : 3LL * c0] + a0.y * z[hi ? N3 + c0 : 3LL * c0 + 1];
+        const v2t a0 = v2[(long long)k0 * 8];
+        acc0 += (double)a0.x * z[hi ? 3LL * c0 + 2 : 3LL * c0] + (double)a0.y * z[hi ? N3 + c0 : 3LL * c0 + 1];
     }
     double acc = acc0 + acc1;
     acc += __shfl_xor(acc, 1, WAVE);  // both lanes of block row `br` hold the row sum
@@ -190,6 +193,15 @@ void dfl_dilu_sweep_color(int forward, I slot0, I nrows_c, const I* rows, I N, c
     const int grid = ceil_div((long long)nrows_c * 8, BLK);
     if (forward) dilu_sweep_kernel<true><<<grid, BLK, 0, S(stream)>>>(slot0, nrows_c, rows, N, eptr, enz, ecol, val, Einv, r, z);
     else dilu_sweep_kernel<false><<<grid, BLK, 0, S(stream)>>>(slot0, nrows_c, rows, N, eptr, enz, ecol, val, Einv, r, z);
+    DFL_LAUNCH_CHECK();
+}
+
+void dfl_dilu_sweep_color_f32(int forward, I slot0, I nrows_c, const I* rows, I N, const I* eptr, const I* enz, const I* ecol,
+                              const float* valf, const T* Einv, const T* r, T* z, void* stream) {
+    if (nrows_c <= 0) return;
+    const int grid = ceil_div((long long)nrows_c * 8, BLK);
+    if (forward) dilu_sweep_kernel<true, float><<<grid, BLK, 0, S(stream)>>>(slot0, nrows_c, rows, N, eptr, enz, ecol, valf, Einv, r, z);
+    else dilu_sweep_kernel<false, float><<<grid, BLK, 0, S(stream)>>>(slot0, nrows_c, rows, N, eptr, enz, ecol, valf, Einv, r, z);
     DFL_LAUNCH_CHECK();
 }
 

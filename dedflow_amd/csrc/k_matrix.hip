@@ -24,6 +24,147 @@ __device__ __forceinline__ d2v ld_val(const d2v* p) {
     return NT ? __builtin_nontemporal_load(p) : *p;
 }
 
+// PERSISTENT form of the matvec (round 3, late; developer A/B, dfl_tune(0, 12 | 13 | 14) -- NOT faster: 0.59-0.62 ms against
+// 0.571 ms back to back).  The question it answers: the counters of the default kernel show 216k waves (10M tets) living
+// 4.8 us each with only 1.8 of them resident per SIMD, and a kernel reading HALF the value bytes (the single-precision copy
+// below) takes the same time with the same number of waves -- is the launch of short-lived waves what paces it?  No: with
+// workgroups that stay, the same rows take longer.  What the two kernels share is the number of L2 requests (3.5e7), one
+// per 128-byte block line or 64-byte half line plus the gathers.  Here a workgroup stays and walks blocks of 32 rows: XCD x (= blockIdx % 8) owns a contiguous slab of
+// row blocks, its W workgroups take blocks j, j + W, ... of the slab (a moving window over val / y), and the row pointers
+// of the next block are requested before the current block's loop.
+template <bool BETA0, bool NT, int U>
+__global__ __launch_bounds__(BLK) void bcsr_spmv_persist_kernel(I row0, I nrows, I N, const I* __restrict__ rp,
+                                                               const I* __restrict__ ci, const T* __restrict__ val, T alpha,
+                                                               const T* __restrict__ x, T beta, T* __restrict__ y) {
+    const int l = threadIdx.x & 7, g = threadIdx.x >> 3;  // lane in the row group, row group in the workgroup (32 of them)
+    const long long N3 = 3LL * N;
+    const int r = l >> 1;
+    const bool hi = (l & 1);
+    const d2v* __restrict__ v2 = reinterpret_cast<const d2v*>(val) + l;
+    const long long nb = ((long long)(nrows - row0) + 31) >> 5;  // blocks of 32 rows
+    const long long per = (nb + 7) >> 3;                         // blocks per XCD slab
+    const long long W = gridDim.x >> 3;                          // workgroups per XCD
+    const long long b0 = (blockIdx.x & 7) * per, b1 = min(nb, b0 + per);
+    long long b = b0 + (blockIdx.x >> 3);
+    if (b >= b1) return;
+    int row = row0 + (int)(b << 5) + g;
+    int s = 0, e = 0;
+    if (row < nrows) { s = rp[row]; e = rp[row + 1]; }
+    for (;;) {
+        const long long bn = b + W;
+        const int rown = row0 + (int)(bn << 5) + g;
+        int sn = 0, en = 0;
+        if (bn < b1 && rown < nrows) { sn = rp[rown]; en = rp[rown + 1]; }  // next block's row pointers: in flight during this block
+        if (row < nrows) {
+            double acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = 0.0;
+            int k = s;
+            for (; k + U <= e; k += U) {
+                int c[U];
+                d2v a[U];
+                double xa[U], xb[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) c[u] = ci[k + u];
+#pragma unroll
+                for (int u = 0; u < U; ++u) a[u] = ld_val<NT>(v2 + (long long)(k + u) * 8);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    xa[u] = x[hi ? 3LL * c[u] + 2 : 3LL * c[u]];
+                    xb[u] = x[hi ? N3 + c[u] : 3LL * c[u] + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u] += a[u].x * xa[u] + a[u].y * xb[u];
+            }
+            for (; k < e; ++k) {
+                const int c0 = ci[k];
+                const d2v a0 = ld_val<NT>(v2 + (long long)k * 8);
+                acc[0] += a0.x * x[hi ? 3LL * c0 + 2 : 3LL * c0] + a0.y * x[hi ? N3 + c0 : 3LL * c0 + 1];
+            }
+            double tot = acc[0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) tot += acc[u];
+            tot += __shfl_xor(tot, 1, WAVE);
+            if (!hi) {
+                const long long yi = xidx(row, r, N3);
+                y[yi] = BETA0 ? alpha * tot : alpha * tot + beta * y[yi];
+            }
+        }
+        if (bn >= b1) break;
+        b = bn; row = rown; s = sn; e = en;
+    }
+}
+
+// ---- single-precision COPY of the block values (PC_TWOLEVEL only: its smoother and its residual matvec read it; the Krylov
+// solver outside is flexible and stays in double precision).  Same lane mapping as the double-precision kernel -- 8 lanes per
+// node row, lane l owns entries (2l, 2l+1) of every block, now one 8-byte load -- half the bytes per matvec.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(BLK) void values_to_f32_kernel(long long n, const T* __restrict__ val, float* __restrict__ valf) {
+    const long long i = ((long long)blockIdx.x * BLK + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const double2 a = *reinterpret_cast<const double2*>(val + i), b = *reinterpret_cast<const double2*>(val + i + 2);
+        *reinterpret_cast<float4*>(valf + i) = make_float4((float)a.x, (float)a.y, (float)b.x, (float)b.y);
+    } else {
+        for (long long k = i; k < n; ++k) valf[k] = (float)val[k];
+    }
+}
+__global__ __launch_bounds__(BLK) void bcsr_spmv_f32_kernel(I nrows, I N, const I* __restrict__ rp, const I* __restrict__ ci,
+                                                           const float* __restrict__ valf, const T* __restrict__ x,
+                                                           T* __restrict__ y) {
+    long long blk = blockIdx.x;
+    const long long per = gridDim.x >> 3;  // grid is a multiple of 8: one contiguous slab of rows per XCD
+    blk = (blk & 7) * per + (blk >> 3);
+    const long long gid = blk * BLK + threadIdx.x;
+    const int row = (int)(gid >> 3);
+    const int l = threadIdx.x & 7;
+    if (row >= nrows) return;  // whole 8-lane groups
+    const long long N3 = 3LL * N;
+    const int r = l >> 1;
+    const bool hi = (l & 1);
+    const int s = rp[row], e = rp[row + 1];
+    const f2v* __restrict__ v2 = reinterpret_cast<const f2v*>(valf) + l;
+    // eight nonzeros in flight per row group: with 8-byte value loads the bytes in flight per wave are those of the
+    // double-precision kernel with four (at U = 4 this kernel took 0.55 ms against 0.59 ms for twice the bytes: latency-bound)
+    constexpr int U = 8;
+    double acc[U] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int k = s;
+    for (; k + U <= e; k += U) {
+        int c[U];
+        f2v a[U];
+        double xa[U], xb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = ci[k + u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(v2 + (long long)(k + u) * 8);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xa[u] = x[hi ? 3LL * c[u] + 2 : 3LL * c[u]];
+            xb[u] = x[hi ? N3 + c[u] : 3LL * c[u] + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] += (double)a[u].x * xa[u] + (double)a[u].y * xb[u];
+    }
+    for (; k + 4 <= e; k += 4) {
+        int c[4];
+        f2v a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = ci[k + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = __builtin_nontemporal_load(v2 + (long long)(k + u) * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            acc[u] += (double)a[u].x * x[hi ? 3LL * c[u] + 2 : 3LL * c[u]] + (double)a[u].y * x[hi ? N3 + c[u] : 3LL * c[u] + 1];
+    }
+    for (; k < e; ++k) {
+        const int c0 = ci[k];
+        const f2v a0 = __builtin_nontemporal_load(v2 + (long long)k * 8);
+        acc[0] += (double)a0.x * x[hi ? 3LL * c0 + 2 : 3LL * c0] + (double)a0.y * x[hi ? N3 + c0 : 3LL * c0 + 1];
+    }
+    double tot = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    tot += __shfl_xor(tot, 1, WAVE);
+    if (!hi) y[xidx(row, r, N3)] = tot;
+}
+
 // U nodal nonzeros per loop trip: all U index loads, then all U value loads, then the 2U
 // gathers are issued before the first FMA -- more bytes in flight per 8-lane row group
 // STORE: 0 = every row group stores its 4 results itself (3 x 8 B + 8 B per row: two partial 128-B lines per wave
@@ -558,6 +699,15 @@ void dfl_bcsr_spmv_range(I row0, I row1, I N, const I* rp, const I* ci, const T*
             case 9: bcsr_spmv_kernel<true, true, 4, true, 0, 512><<<(grid + 4095) / 4096 * 4096, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
             case 10: bcsr_spmv_kernel<true, true, 4, true, 3, 64><<<(grid + 511) / 512 * 512, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
             case 11: bcsr_spmv_kernel<true, true, 4, true, 0, 8><<<(grid + 63) / 64 * 64, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
+            case 12: case 13: case 14: {  // persistent workgroups: 8 / 16 / 4 per CU
+                static int cus = 0;
+                if (!cus) { int dev = 0; DFL_GUARD(hipGetDevice(&dev)); DFL_GUARD(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)); if (cus < 8) cus = 8; }
+                const int wg_per_cu = g_spmv_variant == 12 ? 8 : g_spmv_variant == 13 ? 16 : 4;
+                int gp = (cus * wg_per_cu) / 8 * 8;
+                if (gp > grid8) gp = grid8;
+                bcsr_spmv_persist_kernel<true, true, 4><<<gp, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y);
+                break;
+            }
             default: bcsr_spmv_kernel<true, true, 4, true><<<grid8, BLK, 0, S(stream)>>>(row0, nrows, N, rp, ci, val, alpha, x, beta, y); break;
         }
     } else {
@@ -642,6 +792,18 @@ void dfl_tune(int key, int value) {
     if (key == 0) g_spmv_variant = value;
     if (key == 1) g_pc_apply_mode = value;
     if (key == 2) g_rhs_lane_grid_cap = value;  // workgroups of the persistent residual kernel (0 = as many as are resident)
+}
+void dfl_bcsr_values_to_f32(int64_t n, const T* val, float* valf, void* stream) {
+    if (n <= 0) return;
+    values_to_f32_kernel<<<(unsigned)((n / 4 + BLK) / BLK), BLK, 0, S(stream)>>>(n, val, valf);
+    DFL_LAUNCH_CHECK();
+}
+void dfl_bcsr_spmv_f32(I nrows, I N, const I* rp, const I* ci, const float* valf, const T* x, T* y, void* stream) {
+    if (nrows <= 0) return;
+    const long long groups = ((long long)nrows * 8 + BLK - 1) / BLK;
+    const unsigned grid8 = (unsigned)((groups + 7) / 8 * 8);
+    bcsr_spmv_f32_kernel<<<grid8, BLK, 0, S(stream)>>>(nrows, N, rp, ci, valf, x, y);
+    DFL_LAUNCH_CHECK();
 }
 void dfl_bcsr_spmv(I N, const I* rp, const I* ci, const T* val, T alpha, const T* x, T beta, T* y, void* stream) {
     dfl_bcsr_spmv_rows(N, N, rp, ci, val, alpha, x, beta, y, stream);

@@ -21,6 +21,7 @@ typedef struct PCDilu {
     index_type *d_lptr, *d_lnz, *d_lcol; /* device: strictly-lower (by color) neighbours of each row slot */
     index_type *d_uptr, *d_unz, *d_ucol; /* device: strictly-upper neighbours */
     f64* d_Einv;              /* device [N][16] */
+    const float* valf;        /* PCDILUSetF32Values: the sweeps read the off-diagonal blocks from this single-precision copy */
 } PCDilu;
 
 static void dilu_build_colors(PCDilu* d) {
@@ -144,12 +145,21 @@ static void dilu_apply(PC* pc, value_type* x, value_type* y) {
     const f64* val = MatrixFSBlockValues((Matrix*)pc->mat);
     hipStream_t s = DflStream();
     const index_type n = d->n_active > 0 ? d->n_active : d->n;
-    for (index_type c = 0; c < d->num_color; ++c)
-        dfl_dilu_sweep_color(1, d->color_offset[c], d->color_offset[c + 1] - d->color_offset[c], d->d_rows, d->N, d->d_lptr, d->d_lnz,
-                             d->d_lcol, val, d->d_Einv, x, y, s);
-    for (index_type c = d->num_color - 1; c >= 0; --c)
-        dfl_dilu_sweep_color(0, d->color_offset[c], d->color_offset[c + 1] - d->color_offset[c], d->d_rows, d->N, d->d_uptr, d->d_unz,
-                             d->d_ucol, val, d->d_Einv, x, y, s);
+    if (d->valf) {
+        for (index_type c = 0; c < d->num_color; ++c)
+            dfl_dilu_sweep_color_f32(1, d->color_offset[c], d->color_offset[c + 1] - d->color_offset[c], d->d_rows, d->N, d->d_lptr,
+                                     d->d_lnz, d->d_lcol, d->valf, d->d_Einv, x, y, s);
+        for (index_type c = d->num_color - 1; c >= 0; --c)
+            dfl_dilu_sweep_color_f32(0, d->color_offset[c], d->color_offset[c + 1] - d->color_offset[c], d->d_rows, d->N, d->d_uptr,
+                                     d->d_unz, d->d_ucol, d->valf, d->d_Einv, x, y, s);
+    } else {
+        for (index_type c = 0; c < d->num_color; ++c)
+            dfl_dilu_sweep_color(1, d->color_offset[c], d->color_offset[c + 1] - d->color_offset[c], d->d_rows, d->N, d->d_lptr,
+                                 d->d_lnz, d->d_lcol, val, d->d_Einv, x, y, s);
+        for (index_type c = d->num_color - 1; c >= 0; --c)
+            dfl_dilu_sweep_color(0, d->color_offset[c], d->color_offset[c + 1] - d->color_offset[c], d->d_rows, d->N, d->d_uptr,
+                                 d->d_unz, d->d_ucol, val, d->d_Einv, x, y, s);
+    }
     if (d->nown < d->N) { /* ghost entries of a Krylov vector stay zero */
         HIPGUARD(hipMemsetAsync(y + 3 * (size_t)d->nown, 0, sizeof(f64) * 3 * (size_t)(d->N - d->nown), s));
         HIPGUARD(hipMemsetAsync(y + 3 * (size_t)d->N + d->nown, 0, sizeof(f64) * (size_t)(d->N - d->nown), s));
@@ -183,6 +193,13 @@ PC* PCCreateDILU(Matrix* mat) {
     return pc;
 }
 
+/* The sweeps of the following applications read the off-diagonal blocks from `valf`, a single-precision copy of the matrix's
+ * block values the CALLER keeps current (dfl_bcsr_values_to_f32 after every change of the matrix) and owns; NULL = back to
+ * the matrix's own double-precision values.  E^-1 (PCSetup) is always formed and applied in double precision.  For a DILU
+ * used as a smoother under a flexible solver (PC_TWOLEVEL); the stand-alone PC_ILU0 never sets it. */
+void PCDILUSetF32Values(PC* pc, const float* valf) {
+    if (pc && pc->type == PC_ILU0) ((PCDilu*)pc->data)->valf = valf;
+}
 void PCDILUSetActiveLength(PC* pc, index_type n_active) {
     if (pc && pc->type == PC_ILU0) ((PCDilu*)pc->data)->n_active = n_active;
 }

@@ -57,6 +57,8 @@ typedef struct PCTwoLevel {
     f64 *d_t, *d_rc, *d_xc;
     index_type inner_maxit;
     f64 inner_rtol;
+    float* d_valf;        /* single-precision copy of the fine block values: smoother sweeps and residual matvec (tl_setup) */
+    int64_t valf_len;
     b32 inner_rtol_given; /* set through PCTwoLevelSetInner: the per-solver default does not replace it */
     b32 inner_jacobi;     /* last level solved by Jacobi-GMRES (small coarse levels) instead of DILU-GMRES */
     int64_t inner_iterations;
@@ -128,6 +130,10 @@ static void tl_release(PCTwoLevel* d) {
     CdamFreeDevice(d->d_t, 0); CdamFreeDevice(d->d_rc, 0); CdamFreeDevice(d->d_xc, 0);
     d->d_agg = d->d_aoff = d->d_anode = d->d_goff = d->d_gidx = NULL;
     d->d_t = d->d_rc = d->d_xc = NULL;
+    if (d->smoother) PCDILUSetF32Values(d->smoother, NULL);
+    CdamFreeDevice(d->d_valf, 0);
+    d->d_valf = NULL;
+    d->valf_len = 0;
     if (d->cksp) KrylovDestroy(d->cksp);
     d->cksp = NULL;
     if (d->Ac) MatrixDestroy(d->Ac);
@@ -408,6 +414,30 @@ static void tl_setup(PC* pc) {
         tl_build(d);
     }
     PCSetup(d->smoother);
+    /* Measured alternative, OFF by default (DFL_TL_F32=1): mixed precision INSIDE the preconditioner -- the smoother's sweeps
+       and the residual matvec of the coarse correction read a single-precision copy of the block values (E^-1, all sums, the
+       Galerkin matrix and everything outside the preconditioner stay double).  The outer solver is flexible and the iteration
+       counts do not move (20 / 20 / 40 at 1.3M / 10M / 50M tets), but neither does the time much: 82 -> 78 ms and 715 -> 688 ms
+       per solve -- the matvec on HALF the value bytes takes 0.55 ms against 0.59 ms with the SAME number of L2 requests
+       (3.5e7, tools/pmc_spmv_f32_vs_f64.sh): these kernels are paced by requests, not by bytes.  Not worth 8 GB at 50M tets
+       and a precision caveat. */
+    {
+        static int f32 = -1;
+        if (f32 < 0) f32 = getenv("DFL_TL_F32") && atoi(getenv("DFL_TL_F32")) == 1;
+        MatrixFS* fsf = (MatrixFS*)A->data;
+        const int64_t len = (int64_t)fsf->spy1x1->nnz * 16;
+        if (f32) {
+            if (d->valf_len != len) {
+                CdamFreeDevice(d->d_valf, 0);
+                d->d_valf = (float*)CdamMallocDevice((ptrdiff_t)len * (ptrdiff_t)sizeof(float));
+                d->valf_len = len;
+            }
+            dfl_bcsr_values_to_f32(len, MatrixFSBlockValues(A), d->d_valf, DflStream());
+            PCDILUSetF32Values(d->smoother, d->d_valf);
+        } else {
+            PCDILUSetF32Values(d->smoother, NULL);
+        }
+    }
     dfl_amg_galerkin(d->c1x1->nnz, d->d_goff, d->d_gidx, MatrixFSBlockValues(A), MatrixFSBlockValues(d->Ac), DflStream());
     /* partitioned: every rank summed the coarse rows of its own aggregates (the lists of the others are empty: zeros) */
     if (d->dist) dist_sum_f64(&d->comm, MatrixFSBlockValues(d->Ac), (int64_t)d->c1x1->nnz * 16);
@@ -422,7 +452,12 @@ static void tl_apply(PC* pc, value_type* r, value_type* z) {
     PCDILUSetActiveLength(d->smoother, n);
     PCApply(d->smoother, r, z);                 /* z = S r (copies the phi / T tail when n > 4N) */
     if (d->dist) d->comm.halo_exchange(d->comm.ctx, z); /* the owned rows of A read ghost entries of z */
-    MatrixMatVec(A, z, d->d_t);                 /* t = A z on the (u,p) part (owned rows); the restriction forms r - t */
+    if (d->d_valf && d->valf_len) {             /* t = A z on the (u,p) part (owned rows); the restriction forms r - t */
+        MatrixFS* fsf = (MatrixFS*)A->data;
+        dfl_bcsr_spmv_f32(MatrixFSOwnedRows(A), N, fsf->spy1x1->row_ptr, fsf->spy1x1->col_ind, d->d_valf, z, d->d_t, s);
+    } else {
+        MatrixMatVec(A, z, d->d_t);
+    }
     dfl_amg_restrict_diff(Nc, d->d_aoff, d->d_anode, N, r, d->d_t, d->d_rc, s);
     /* partitioned: rc is zero outside this rank's aggregates; the sum over ranks is the whole coarse residual, on every rank */
     if (d->dist) dist_sum_f64(&d->comm, d->d_rc, 4 * (int64_t)Nc);

@@ -378,6 +378,8 @@ PC* PCCreateAMGX(Matrix* mat, void* options); /* returns NULL: NVIDIA-only exter
  * of the reference's Jacobi tree (PC_DECOMPOSITION = the reference default). */
 PC* PCCreateDILU(Matrix* mat);
 void PCDILUSetActiveLength(PC* pc, index_type n_active);
+/* sweeps read the off-diagonal blocks from a caller-kept single-precision copy (NULL = the matrix's own values); host/pc_dilu.c */
+void PCDILUSetF32Values(PC* pc, const float* valf);
 index_type PCDILUGetColors(PC* pc, u8* color_out);
 const f64* PCDILUGetInverseBlocks(PC* pc);
 /* PC_TWOLEVEL (host/pc_twolevel.c, csrc/k_amg.hip; build-defined, in the spirit of the AMGX aggregation configuration the

@@ -410,6 +410,14 @@ void dfl_amg_galerkin(dfl_index nnzc, const dfl_index* off, const dfl_index* idx
                       void* stream);
 void dfl_amg_restrict(dfl_index Nc, const dfl_index* aoff, const dfl_index* anode, dfl_index N, const dfl_value* r, dfl_value* rc,
                       void* stream);
+/* single-precision copy of block values (n = nnz1 * 16 entries) and the matvec / DILU sweeps reading it: PC_TWOLEVEL's
+ * smoother and residual matvec (a preconditioner under FGMRES may be inexact; everything outside it stays double) */
+void dfl_bcsr_values_to_f32(int64_t n, const dfl_value* val, float* valf, void* stream);
+void dfl_bcsr_spmv_f32(dfl_index nrows, dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind, const float* valf,
+                       const dfl_value* x, dfl_value* y, void* stream); /* y = A x on rows [0, nrows) */
+void dfl_dilu_sweep_color_f32(int forward, dfl_index slot0, dfl_index nrows_c, const dfl_index* rows, dfl_index N,
+                              const dfl_index* eptr, const dfl_index* enz, const dfl_index* ecol, const float* valf,
+                              const dfl_value* Einv, const dfl_value* r, dfl_value* z, void* stream);
 /* the same of r - sub (the residual r - A z with sub = A z from a plain matvec) */
 void dfl_amg_restrict_diff(dfl_index Nc, const dfl_index* aoff, const dfl_index* anode, dfl_index N, const dfl_value* r,
                            const dfl_value* sub, dfl_value* rc, void* stream);

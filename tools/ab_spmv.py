@@ -18,10 +18,12 @@ x = api.DeviceArray.from_numpy(np.random.default_rng(0).normal(size=6 * P.N))
 y = api.DeviceArray(6 * P.N)
 nbytes = 132.0 * P.nnz1 + 4.0 * (P.N + 1) + 64.0 * P.N
 t = api.Timer()
-NV = 5
-res = {v: [] for v in range(NV)}
+VARS = [int(a) for a in os.environ["AB_SPMV_VARIANTS"].split(",")] if os.environ.get("AB_SPMV_VARIANTS") else list(range(5))
+NV = len(VARS)
+res = {v: [] for v in VARS}
+ref = None
 for rep in range(6):
-    for v in range(NV):
+    for v in VARS:
         L.dfl_tune(0, v)
         P.matvec(x, y)
         t.start()
@@ -29,7 +31,12 @@ for rep in range(6):
             P.matvec(x, y)
         t.stop()
         res[v].append(t.ms() / 10)
-for v in range(NV):
+for v in VARS:
     a = np.array(res[v][1:])
-    print("variant %d (NT=%d U=%d): median %.4f ms  min %.4f  -> %.0f GB/s (%.3f of 8 TB/s)" %
+    print("variant %d (0-4: NT=%d U=%d; 4 = default XCD slabs; 12/13/14 = persistent, 8/16/4 workgroups per CU): median %.4f ms  min %.4f  -> %.0f GB/s (%.3f of 8 TB/s)" %
           (v, 1 if v == 4 else v & 1, 2 if v < 2 else 4, np.median(a), a.min(), nbytes / np.median(a) / 1e6, nbytes / np.median(a) / 1e6 / 8000))
+L.dfl_tune(0, 4); P.matvec(x, y); api.sync(); y4 = y.numpy().copy()
+for v in VARS:
+    L.dfl_tune(0, v); y.zero(); P.matvec(x, y); api.sync()
+    print("variant %d: max |y - y(default)| = %.3e" % (v, np.abs(y.numpy() - y4).max()))
+L.dfl_tune(0, 4)
