@@ -336,7 +336,7 @@ __global__ __launch_bounds__(BLK) void cgs_update_pc_kernel(I nrows, I N, I ncol
                                                            const T* __restrict__ hraw, T* __restrict__ w,
                                                            const T* __restrict__ dinv33, const T* __restrict__ dinv1,
                                                            T* __restrict__ z, I iter, T* H, I ldh, T* gv, T* beta, T* res_hist,
-                                                           T* d_nrm, int* d_flag) {
+                                                           T* d_nrm, int* d_flag, T* __restrict__ z4) {
     __shared__ double sh[GIV_MAX + 2];
     __shared__ double s_col[GIV_MAX], s_gv[2 * GIV_MAX];
     __shared__ double s_nrm;
@@ -371,10 +371,17 @@ __global__ __launch_bounds__(BLK) void cgs_update_pc_kernel(I nrows, I N, I ncol
         a0 *= s; a1 *= s; a2 *= s; ap *= s;
         w[3 * i] = a0; w[3 * i + 1] = a1; w[3 * i + 2] = a2; w[3LL * N + i] = ap;
         const T* A = dinv33 + i * 9;
-        z[3 * i + 0] = A[0] * a0 + A[3] * a1 + A[6] * a2;
-        z[3 * i + 1] = A[1] * a0 + A[4] * a1 + A[7] * a2;
-        z[3 * i + 2] = A[2] * a0 + A[5] * a1 + A[8] * a2;
-        z[3LL * N + i] = ap * dinv1[i];
+        const double z0 = A[0] * a0 + A[3] * a1 + A[6] * a2, z1 = A[1] * a0 + A[4] * a1 + A[7] * a2;
+        const double z2 = A[2] * a0 + A[5] * a1 + A[8] * a2, zp = ap * dinv1[i];
+        z[3 * i + 0] = z0;
+        z[3 * i + 1] = z1;
+        z[3 * i + 2] = z2;
+        z[3LL * N + i] = zp;
+        if (z4) {  // the interleaved copy the matvec gathers from (dfl_bcsr_spmv_x4)
+            double2* o = reinterpret_cast<double2*>(z4 + 4 * i);
+            o[0] = make_double2(z0, z1);
+            o[1] = make_double2(z2, zp);
+        }
     }
     if (blockIdx.x == 0) {  // uniform per block: the barriers inside givens_step_block are safe
         T* col = H + (long long)iter * ldh;
@@ -802,6 +809,12 @@ void dfl_gmres_givens_sq(I iter, T* d_nrm_sq, T* d_H, I ldh, T* d_gv, T* d_beta,
 }
 void dfl_cgs_update_pc_givens(I nrows, I N, I ncol, const T* Q, int64_t ldq, const T* d_hraw, T* w, const T* dinv33, const T* dinv1,
                               T* z, I iter, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, T* d_nrm, int* d_flag, void* stream) {
+    dfl_cgs_update_pc_givens_x4(nrows, N, ncol, Q, ldq, d_hraw, w, dinv33, dinv1, z, nullptr, iter, d_H, ldh, d_gv, d_beta, d_res_hist,
+                                d_nrm, d_flag, stream);
+}
+void dfl_cgs_update_pc_givens_x4(I nrows, I N, I ncol, const T* Q, int64_t ldq, const T* d_hraw, T* w, const T* dinv33,
+                                 const T* dinv1, T* z, T* z4, I iter, T* d_H, I ldh, T* d_gv, T* d_beta, T* d_res_hist, T* d_nrm,
+                                 int* d_flag, void* stream) {
     if (ncol + 1 > GIV_MAX + 2 || nrows <= 0) abort();  // the caller falls back to the separate kernels beyond GIV_MAX columns
     // DFL_UPDATE_PC: 0 = one node per thread (default), 1 = two nodes per thread (16-byte loads), 2 = + newest column first.
     // Measured on rank 0 / rank 4 of the 8-way 10M-tet partition (gpurun_out/r3c, profiles/r03_rank_local_*): 7.99 / 7.39 ms
@@ -811,9 +824,9 @@ void dfl_cgs_update_pc_givens(I nrows, I N, I ncol, const T* Q, int64_t ldq, con
     static int variant = -1;
     if (variant < 0) { const char* e = getenv("DFL_UPDATE_PC"); variant = e ? atoi(e) : 0; }
     const int grid2 = (int)ceil_div((nrows + 1) / 2, BLK);
-    if (variant == 0)
+    if (variant == 0 || z4)
         cgs_update_pc_kernel<<<ceil_div(nrows, BLK), BLK, 0, S(stream)>>>(nrows, N, ncol, Q, ldq, d_hraw, w, dinv33, dinv1, z, iter, d_H, ldh,
-                                                                          d_gv, d_beta, d_res_hist, d_nrm, d_flag);
+                                                                          d_gv, d_beta, d_res_hist, d_nrm, d_flag, z4);
     else if (variant == 1)
         cgs_update_pc2_kernel<false><<<grid2, BLK, 0, S(stream)>>>(nrows, N, ncol, Q, ldq, d_hraw, w, dinv33, dinv1, z, iter, d_H, ldh, d_gv,
                                                                    d_beta, d_res_hist, d_nrm, d_flag);

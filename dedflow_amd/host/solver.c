@@ -349,6 +349,27 @@ static b32 jacobi_tree_data(PC* pc, const f64** d33, const f64** d1, index_type*
 }
 
 /* z = M^{-1} (w / *d_nrm), q_out = w / *d_nrm   (d_nrm == NULL: no scaling) */
+/* z4 != NULL: the application may ALSO leave z interleaved ([node][4], owned rows) for the matvec that follows
+ * (DflMatrixFSMatVecX4Range); returns TRUE when it did -- the Jacobi tree writes it from registers -- FALSE when the caller has
+ * to make the copy itself (dfl_interleave4) */
+b32 DflPcApplyFusedX4(PC* pc, index_type na, f64* w, const f64* d_nrm, f64* z, f64* z4) {
+    index_type N;
+    if (pc && pc->type == PC_DECOMPOSITION && decomposition_is_fused_up((PCDecomposition*)pc->data, &N)) {
+        PCDecomposition* d = (PCDecomposition*)pc->data;
+        const f64* d33 = (const f64*)((PCJacobi*)d->pc[0]->data)->diag;
+        const f64* d1 = (const f64*)((PCJacobi*)d->pc[1]->data)->diag;
+        const index_type nrows = MatrixFSOwnedRows((Matrix*)pc->mat);
+        if (z4) {
+            dfl_pc_jacobi_apply_scaled_rows_x4(nrows, N, na, d33, d1, w, d_nrm, w, z, z4, DflStream());
+            return TRUE;
+        }
+        if (d_nrm) dfl_pc_jacobi_apply_scaled_rows(nrows, N, na, d33, d1, w, d_nrm, w, z, DflStream());
+        else dfl_pc_jacobi_apply_rows(nrows, N, na, d33, d1, w, z, DflStream());
+        return FALSE;
+    }
+    DflPcApplyFused(pc, na, w, d_nrm, z);
+    return FALSE;
+}
 void DflPcApplyFused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64* z) {
     index_type N;
     if (pc && pc->type == PC_DECOMPOSITION && decomposition_is_fused_up((PCDecomposition*)pc->data, &N)) {
@@ -683,6 +704,18 @@ static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe) {
                         fj_rows <= 500000; /* measured: 38 us against 31 + 7 + 6 us for the three kernels at 227k owned nodes, but
                                               274 us against 192 + 46 + 10 us at 1.73M (the node-per-thread mapping streams the
                                               basis with 8-byte loads): large ranks keep the three launches */
+    static int x4_env = -1, x4_min = 4096; /* DFL_SPMV_X4=0: the reference-layout gathers (A/B); DFL_SPMV_X4_MIN: smallest
+                                               matrix (nodes) that takes the interleaved path (tests set 1) */
+    if (x4_env < 0) {
+        x4_env = !(getenv("DFL_SPMV_X4") && atoi(getenv("DFL_SPMV_X4")) == 0);
+        if (getenv("DFL_SPMV_X4_MIN")) x4_min = atoi(getenv("DFL_SPMV_X4_MIN"));
+    }
+    const index_type x4_N = MatrixFSBlockValues(A) ? ((MatrixFS*)A->data)->spy1x1->num_row : 0;
+    const b32 x4_path = x4_env && !dist && !fuse_pc && x4_N >= x4_min && MatrixFSOwnedRows(A) == x4_N && na >= 4 * x4_N;
+    /* partitioned, split rows: the same gathers; owned part of the copy from the producer, ghost part behind the unpack */
+    const index_type x4_owned = dist ? MatrixFSOwnedRows(A) : x4_N;
+    const b32 x4_dist = x4_env && dist && split_rows && x4_N >= x4_min && na >= 4 * x4_N;
+    f64* const z4d = x4_dist ? DflMatrixFSInterleavedScratch(A) : NULL;
     for (index_type cycle = 0; !converged && total < maxit; ++cycle) {
         f64* res_hist = ex->res_hist + total; /* history of this cycle */
         index_type iter = 0;
@@ -730,35 +763,65 @@ static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe) {
         while (!converged && iter < m && total < maxit) {
             /* 2.0 tmp = inv(P) Q[:,iter]   2.2 Q[:,iter+1] = A tmp */
             f64* const zk = Zb ? ZCOL(iter) : tmp; /* FGMRES keeps every preconditioned vector */
-            if (!z_ready) DFL_TIMED(DFL_TAG_PC, DflPcApplyFused(pc, na, QCOL(iter), ex->nrm + iter, zk));
+            if (x4_path) {
+                /* one GPU: the matvec gathers from an interleaved copy of z (one 16-byte load per lane and nonzero instead of two
+                   8-byte loads: 0.50 against 0.57 ms at 10M tets); the Jacobi tree writes it from registers, any other
+                   preconditioner is followed by one interleave pass */
+                f64* const z4 = DflMatrixFSInterleavedScratch(A);
+                b32 wrote = FALSE;
+                DFL_TIMED(DFL_TAG_PC, wrote = DflPcApplyFusedX4(pc, na, QCOL(iter), ex->nrm + iter, zk, z4));
+                if (!wrote) dfl_interleave4(0, x4_N, x4_N, zk, z4, s);
+                DFL_TIMED(DFL_TAG_SPMV, DflMatrixFSMatVecX4Range(A, z4, QCOL(iter + 1), 0, x4_N));
+                goto matvec_done;
+            }
+            if (!z_ready) {
+                b32 wrote = FALSE;
+                DFL_TIMED(DFL_TAG_PC, wrote = DflPcApplyFusedX4(pc, na, QCOL(iter), ex->nrm + iter, zk, x4_dist ? z4d : NULL));
+                if (x4_dist && !wrote) dfl_interleave4(0, x4_owned, x4_N, zk, z4d, s);
+            }
             if (dist && split_rows) {
-                /* interior rows read no ghost entry: they run while the halo is in flight */
+                /* interior rows read no ghost entry: they run while the halo is in flight.  x4_dist: the rows gather from the
+                   interleaved copy z4d -- its owned part was written by the producer of zk (before halo_begin), its ghost part is
+                   made behind the unpack, on the stream the boundary rows run on */
                 if (ex->comm.halo_begin) ex->comm.halo_begin(ex->comm.ctx, zk);
                 else ex->comm.halo_exchange(ex->comm.ctx, zk);
-                DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, zk, QCOL(iter + 1), 0, n_interior));
+                if (x4_dist) DFL_TIMED(DFL_TAG_SPMV, DflMatrixFSMatVecX4Range(A, z4d, QCOL(iter + 1), 0, n_interior));
+                else DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, zk, QCOL(iter + 1), 0, n_interior));
                 hipStream_t side = (ex->comm.halo_begin && ex->comm.halo_stream && !side_rows_off) ? ex->comm.halo_stream(ex->comm.ctx) : NULL;
                 if (side) {
                     /* the boundary rows go behind the unpack on the exchange's own stream: they write rows the interior launch
                        does not touch and read ghost entries it does not read, so the two overlap; halo_end joins both */
                     DflSetStream(side);
-                    MatrixFSMatVecRange(A, zk, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A));
+                    if (x4_dist) {
+                        dfl_interleave4(x4_owned, x4_N, x4_N, zk, z4d, side);
+                        DflMatrixFSMatVecX4Range(A, z4d, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A));
+                    } else {
+                        MatrixFSMatVecRange(A, zk, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A));
+                    }
                     DflSetStream(s);
                     ex->comm.halo_end(ex->comm.ctx, zk);
                 } else {
                     if (ex->comm.halo_begin) ex->comm.halo_end(ex->comm.ctx, zk);
-                    DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, zk, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A)));
+                    if (x4_dist) {
+                        dfl_interleave4(x4_owned, x4_N, x4_N, zk, z4d, s);
+                        DFL_TIMED(DFL_TAG_SPMV, DflMatrixFSMatVecX4Range(A, z4d, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A)));
+                    } else {
+                        DFL_TIMED(DFL_TAG_SPMV, MatrixFSMatVecRange(A, zk, QCOL(iter + 1), n_interior, MatrixFSOwnedRows(A)));
+                    }
                 }
             } else {
                 if (dist) ex->comm.halo_exchange(ex->comm.ctx, zk);
                 DFL_TIMED(DFL_TAG_SPMV, MatrixMatVec(A, zk, QCOL(iter + 1)));
             }
+        matvec_done:
             /* 3. classical Gram-Schmidt */
             if (fuse_pc) {
                 DFL_TIMED(DFL_TAG_CGS_DOTS, dfl_cgs_dots(na, iter + 2, Q, na, QCOL(iter + 1), ex->hraw, ex->work, s));
                 if (dist) ex->comm.allreduce_sum(ex->comm.ctx, ex->hraw, iter + 2);
                 DFL_TIMED(DFL_TAG_CGS_UPDATE,
-                          dfl_cgs_update_pc_givens(fj_rows, fj_N, iter + 1, Q, na, ex->hraw, QCOL(iter + 1), fj_d33, fj_d1, tmp, iter, H, ldh,
-                                                   ex->gv, ex->beta, res_hist, ex->nrm + iter + 1, ex->d_flag, s));
+                          dfl_cgs_update_pc_givens_x4(fj_rows, fj_N, iter + 1, Q, na, ex->hraw, QCOL(iter + 1), fj_d33, fj_d1, tmp,
+                                                      x4_dist ? z4d : NULL, iter, H, ldh, ex->gv, ex->beta, res_hist,
+                                                      ex->nrm + iter + 1, ex->d_flag, s));
                 z_ready = TRUE;
                 goto arnoldi_step_done;
             }

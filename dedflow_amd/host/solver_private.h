@@ -47,6 +47,7 @@ typedef struct KrylovExt {
 int DflWsInPool(void);
 void DflWsVecFreeAs(f64* p, int pooled);
 void DflPcApplyFused(PC* pc, index_type na, f64* w, const f64* d_nrm, f64* z);
+b32 DflPcApplyFusedX4(PC* pc, index_type na, f64* w, const f64* d_nrm, f64* z, f64* z4); /* TRUE: z4 written too */
 PC* DflKrylovBuildPC(Krylov* ksp, Matrix* A);            /* the (re)build step of KrylovSolve */
 b32 DflKrylovEnsureWorkspace(Krylov* ksp, Matrix* A, index_type* n, index_type* m, index_type* ldh);
 void DflKrylovMarkInner(Krylov* ksp);

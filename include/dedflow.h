@@ -277,6 +277,8 @@ struct MatrixFS {
     b32 reference_layout;  /* MatrixFSUseReferenceLayout: keep the four row-expanded sub-matrix arrays (no block mode) */
     b32 block_val_heap;    /* block_val is a plain hipMalloc block (moved out of the allocator's pool by the Krylov placement
                               calibration, host/solver.c) -- MatrixDestroy frees it accordingly */
+    value_type* x4;        /* [num_row][4] interleaved copy of the matvec's input (dfl_bcsr_spmv_x4), allocated on first use */
+    b32 x4_pool;           /* x4 came from the allocator's pool (DFL_X4_POOL=1) rather than from hipMalloc */
 };
 Matrix* MatrixCreateTypeCSR(const CSRAttr* attr, void*);
 Matrix* MatrixCreateTypeFS(index_type n_offset, const index_type* offset, void*);
@@ -288,6 +290,11 @@ void MatrixAMVPBY(Matrix* A, value_type alpha, value_type* x, value_type beta, v
 void MatrixAMVPBYWithMask(Matrix* A, value_type alpha, value_type* x, value_type beta, value_type* y, value_type* left_mask,
                           value_type* right_mask);
 void MatrixMatVec(Matrix* matrix, value_type* x, value_type* y);
+/* block-mode (u,p) MatrixFS: the interleaved scratch the matvec gathers from (allocated on first call), and y = A x with the
+ * scratch already filled by the caller for all columns the rows [row0, row1) read (dfl_interleave4, or a producer that
+ * writes both layouts, e.g. dfl_pc_jacobi_apply_scaled_rows_x4) */
+value_type* DflMatrixFSInterleavedScratch(Matrix* matrix);
+void DflMatrixFSMatVecX4Range(Matrix* matrix, const value_type* x4, value_type* y, index_type row0, index_type row1);
 void MatrixMatVecWithMask(Matrix* matrix, value_type* x, value_type* y, value_type* left_mask, value_type* right_mask);
 void MatrixGetDiag(Matrix* matrix, value_type* diag, index_type bs);
 void MatrixSetValuesCOO(Matrix* matrix, value_type alpha, index_type n, const index_type* row, const index_type* col,

@@ -116,6 +116,11 @@ void dfl_cgs_update_pc_givens(dfl_index nrows, dfl_index N, dfl_index ncol, cons
                               dfl_value* w, const dfl_value* dinv33, const dfl_value* dinv1, dfl_value* z, dfl_index iter,
                               dfl_value* d_H, dfl_index ldh, dfl_value* d_gv, dfl_value* d_beta, dfl_value* d_res_hist,
                               dfl_value* d_nrm, int* d_flag, void* stream);
+/* the same, also writing z interleaved into z4[node][4] (owned rows) for dfl_bcsr_spmv_x4; z4 == NULL: as above */
+void dfl_cgs_update_pc_givens_x4(dfl_index nrows, dfl_index N, dfl_index ncol, const dfl_value* Q, int64_t ldq, const dfl_value* d_hraw,
+                                 dfl_value* w, const dfl_value* dinv33, const dfl_value* dinv1, dfl_value* z, dfl_value* z4,
+                                 dfl_index iter, dfl_value* d_H, dfl_index ldh, dfl_value* d_gv, dfl_value* d_beta,
+                                 dfl_value* d_res_hist, dfl_value* d_nrm, int* d_flag, void* stream);
 void dfl_gmres_givens_pythagoras(dfl_index iter, dfl_value* d_nrm, dfl_value* d_H, dfl_index ldh, dfl_value* d_gv,
                                  dfl_value* d_beta, dfl_value* d_res_hist, int* d_flag, void* stream);
 /* back substitution H[0:m,0:m] y = beta[0:m] in place on beta (cublasDtrsv, krylov.c:297-301) */
@@ -410,6 +415,18 @@ void dfl_amg_galerkin(dfl_index nnzc, const dfl_index* off, const dfl_index* idx
                       void* stream);
 void dfl_amg_restrict(dfl_index Nc, const dfl_index* aoff, const dfl_index* anode, dfl_index N, const dfl_value* r, dfl_value* rc,
                       void* stream);
+/* The matvec with x gathered from an INTERLEAVED copy x4[node][4] = (u0 u1 u2 p): the two lanes of a block row fetch their x
+ * entries with one 16-byte load each instead of two 8-byte loads from the u part and the p part of the reference layout --
+ * one gather instruction and about one L2 request less per nodal nonzero: 0.50 against 0.57 ms at 10M tets (6.95 TB/s),
+ * bitwise the same y.  dfl_interleave4 writes the copy for nodes [node0, node1); y rows [row0, row1) = alpha * A x. */
+/* the fused Jacobi-tree application (dfl_pc_jacobi_apply[_scaled]_rows; d_nrm == NULL: unscaled, q_out unused) that ALSO
+ * writes y interleaved into y4[node][4] for the owned rows -- the matvec that follows needs no interleave pass */
+void dfl_pc_jacobi_apply_scaled_rows_x4(dfl_index nrows, dfl_index N, dfl_index n, const dfl_value* dinv33, const dfl_value* dinv1,
+                                        const dfl_value* w, const dfl_value* d_nrm, dfl_value* q_out, dfl_value* y, dfl_value* y4,
+                                        void* stream);
+void dfl_interleave4(dfl_index node0, dfl_index node1, dfl_index N, const dfl_value* x, dfl_value* x4, void* stream);
+void dfl_bcsr_spmv_x4(dfl_index row0, dfl_index row1, dfl_index N, const dfl_index* row_ptr, const dfl_index* col_ind,
+                      const dfl_value* val, dfl_value alpha, const dfl_value* x4, dfl_value* y, void* stream);
 /* single-precision copy of block values (n = nnz1 * 16 entries) and the matvec / DILU sweeps reading it: PC_TWOLEVEL's
  * smoother and residual matvec (a preconditioner under FGMRES may be inexact; everything outside it stays double) */
 void dfl_bcsr_values_to_f32(int64_t n, const dfl_value* val, float* valf, void* stream);

@@ -80,6 +80,17 @@ def test_distributed_fused_norm_option_gpu_gloo(oracle_lib, fused_kernel):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,world", [("gpu", 2), ("gpu_rccl", 1), ("gpu_twolevel", 2)])
+def test_distributed_interleaved_matvec_gpu(mode, world, oracle_lib):
+    """The matvec gathering from the interleaved copy of its input (dfl_bcsr_spmv_x4; by default only for >= 4096 nodes) forced
+    onto the small test meshes: partitioned GMRES with split rows (owned part of the copy from the producer kernel, ghost part
+    behind the unpack), the C-level RCCL communicator with its side stream, and FGMRES + PC_TWOLEVEL -- same checks as the
+    default path (the result is bitwise the same matvec)."""
+    out = _launch(mode, world, 14 if mode == "gpu_twolevel" else 8, 0 if mode == "gpu_twolevel" else 30, extra_env={"DFL_SPMV_X4_MIN": "1"})
+    assert {"gpu": "DIST_GPU_OK", "gpu_rccl": "DIST_RCCL_OK", "gpu_twolevel": "DIST_TWOLEVEL_OK"}[mode] in out
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_twolevel_gpu_gloo(world, oracle_lib):
     """PC_TWOLEVEL on element-partitioned matrices: per-rank aggregates, replicated Galerkin coarse
