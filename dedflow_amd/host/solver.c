@@ -297,7 +297,8 @@ static void ws_ensure(KrylovExt* x, index_type n, index_type maxit, index_type l
     if (x->ws_n == n && x->ws_maxit == maxit && x->ws_hist >= hist && x->ws_pooled == DflWsInPool()) return;
     ws_free(x);
     x->ws_pooled = DflWsInPool();
-    x->Q = ws_vec_malloc((ptrdiff_t)n * (maxit + 1));
+    x->Q = ws_vec_malloc((ptrdiff_t)n * (maxit + 2)); /* + one column: the interleaved copy z4 the matvec gathers from shares
+                                                          the basis block, and with it the placement the calibration chose */
     x->q_pooled = x->ws_pooled;
     x->H = (f64*)CdamMallocDevice((ptrdiff_t)ldh * maxit * SIZE_OF(f64));
     x->tmp = ws_vec_malloc((ptrdiff_t)n * 2);
@@ -648,7 +649,7 @@ static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe) {
     }
     if (ex->ws_fresh) {
         ex->ws_fresh = FALSE;
-        if (!ex->flexible && !ex->no_calibration) ex->Q = DflWsPickBasis(ex, A, pc, ex->Q, (ptrdiff_t)n * (m + 1), na, m, ldh);
+        if (!ex->flexible && !ex->no_calibration) ex->Q = DflWsPickBasis(ex, A, pc, ex->Q, (ptrdiff_t)n * (m + 2), na, m, ldh);
     }
     if (ex->flexible && !ex->Z) ex->Z = ws_vec_malloc((ptrdiff_t)n * m);
     f64* const Zb = ex->flexible ? ex->Z : NULL;
@@ -715,7 +716,7 @@ static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe) {
     /* partitioned, split rows: the same gathers; owned part of the copy from the producer, ghost part behind the unpack */
     const index_type x4_owned = dist ? MatrixFSOwnedRows(A) : x4_N;
     const b32 x4_dist = x4_env && dist && split_rows && x4_N >= x4_min && na >= 4 * x4_N;
-    f64* const z4d = x4_dist ? DflMatrixFSInterleavedScratch(A) : NULL;
+    f64* const z4d = x4_dist ? Q + (size_t)na * (size_t)(m + 1) : NULL; /* the spare column of the basis block */
     for (index_type cycle = 0; !converged && total < maxit; ++cycle) {
         f64* res_hist = ex->res_hist + total; /* history of this cycle */
         index_type iter = 0;
@@ -767,7 +768,7 @@ static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe) {
                 /* one GPU: the matvec gathers from an interleaved copy of z (one 16-byte load per lane and nonzero instead of two
                    8-byte loads: 0.50 against 0.57 ms at 10M tets); the Jacobi tree writes it from registers, any other
                    preconditioner is followed by one interleave pass */
-                f64* const z4 = DflMatrixFSInterleavedScratch(A);
+                f64* const z4 = Q + (size_t)na * (size_t)(m + 1); /* the spare column of the basis block */
                 b32 wrote = FALSE;
                 DFL_TIMED(DFL_TAG_PC, wrote = DflPcApplyFusedX4(pc, na, QCOL(iter), ex->nrm + iter, zk, z4));
                 if (!wrote) dfl_interleave4(0, x4_N, x4_N, zk, z4, s);

@@ -53,11 +53,19 @@ typedef struct Loop {
     Matrix* A;
     PC* pc;
     index_type na, m, ldh;
+    index_type n;  /* column stride of the basis block */
+    index_type x4; /* > 0: the solver's matvec gathers from the interleaved copy (nodes of the unpartitioned block matrix) */
     hipEvent_t a, b;
 } Loop;
 
 static void loop_open(Loop* L, KrylovExt* ex, Matrix* A, PC* pc, index_type na, index_type m, index_type ldh) {
     L->ex = ex; L->A = A; L->pc = pc; L->na = na; L->m = m; L->ldh = ldh;
+    L->n = na;
+    {   /* the conditions of gmres_run's x4_path (one GPU, block values, not switched off) */
+        const index_type N = MatrixFSBlockValues(A) ? ((MatrixFS*)A->data)->spy1x1->num_row : 0;
+        const b32 off = getenv("DFL_SPMV_X4") && atoi(getenv("DFL_SPMV_X4")) == 0;
+        L->x4 = (!off && !ex->has_comm && !ex->fused_norm && N >= 4096 && MatrixFSOwnedRows(A) == N && na >= 4 * N) ? N : 0;
+    }
     HIPGUARD(hipEventCreate(&L->a));
     HIPGUARD(hipEventCreate(&L->b));
     const f64 one = 1.0;
@@ -83,10 +91,18 @@ static float time_block(const Loop* L, f64* Qk) {
         f64* y = Qk + (size_t)col * (size_t)na;
         dfl_cgs_dots(na, 6, Qk, na, w, ex->H, ex->work, s);
         dfl_cgs_update(na, 6, Qk, na, ex->H, w, ex->nrm + 1, 1, ex->work, s);
-        DflPcApplyFused(L->pc, na, w, ex->nrm, ex->tmp);
-        HIPGUARD(hipEventRecord(L->a, s));
-        MatrixMatVec(L->A, ex->tmp, y);
-        HIPGUARD(hipEventRecord(L->b, s));
+        if (L->x4) { /* as the solver does it: the interleaved copy in the spare column of THIS block, written by the PC kernel */
+            f64* z4 = Qk + (size_t)(m + 1) * (size_t)na;
+            if (!DflPcApplyFusedX4(L->pc, na, w, ex->nrm, ex->tmp, z4)) dfl_interleave4(0, L->x4, L->x4, ex->tmp, z4, s);
+            HIPGUARD(hipEventRecord(L->a, s));
+            DflMatrixFSMatVecX4Range(L->A, z4, y, 0, L->x4);
+            HIPGUARD(hipEventRecord(L->b, s));
+        } else {
+            DflPcApplyFused(L->pc, na, w, ex->nrm, ex->tmp);
+            HIPGUARD(hipEventRecord(L->a, s));
+            MatrixMatVec(L->A, ex->tmp, y);
+            HIPGUARD(hipEventRecord(L->b, s));
+        }
         HIPGUARD(hipEventSynchronize(L->b));
         HIPGUARD(hipEventElapsedTime(&ms, L->a, L->b));
         if (rep > 0) sum_ms += ms;
@@ -228,7 +244,7 @@ void DflKrylovCalibratePlacement(Krylov* ksp, Matrix* A, int64_t max_extra_bytes
     ex->ws_fresh = FALSE;                          /* the first solve does not calibrate again */
     if (ex->flexible || !eligible(ex, A, na, m)) return;
     hipStream_t s = DflStream();
-    const ptrdiff_t count = (ptrdiff_t)n * (m + 1);
+    const ptrdiff_t count = (ptrdiff_t)n * (m + 2); /* (+ the spare column of the interleaved matvec input, as ws_ensure) */
     const size_t bytes = (size_t)count * sizeof(f64);
     Budget bud = {max_extra_bytes > 0 ? (size_t)max_extra_bytes : ~(size_t)0, 0};
     double settle_cap = 10.0;
