@@ -15,7 +15,7 @@ cd $REPO
 python3 - $OUT $M <<'PY'
 import csv, glob, json, sys, collections
 out, M = sys.argv[1], int(sys.argv[2])
-groups = {"spmv": "bcsr_spmv_kernel", "asm_lhs": "tet_lhs_slot_kernel", "asm_rhs": "tet_rhs_lane_kernel",
+groups = {"spmv": "bcsr_spmv_x4_kernel", "asm_lhs": "tet_lhs_slot_kernel", "asm_rhs": "tet_rhs_lane_kernel",
           "rhs_node_sum": "rhs_node_sum_kernel", "cgs_dots": "cgs_dots_stage1", "cgs_update": "cgs_update_kernel<true",
           "pc_apply": "pc_apply_kernel", "daxpy_calibration": "map3<"}
 acc = {g: {"FETCH_SIZE": [], "WRITE_SIZE": []} for g in groups}
