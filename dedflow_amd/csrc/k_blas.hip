@@ -156,6 +156,52 @@ __global__ __launch_bounds__(BLK) void cgs_dots_stage1(I n, I ncol, const T* __r
     }
 }
 
+// The same partial sums with ALL loads of a column tile issued before the first reduction: the kernel above runs a
+// workgroup reduction (two barriers) after every column, so only the 4 loads of one column are in flight per thread; here
+// the CT * RPT loads of the tile are, and one barrier serves the eight sums.  Same additions in the same order per column:
+// bitwise the same partial sums.
+template <int MODE = 0>
+__global__ __launch_bounds__(BLK) void cgs_dots_stage1_tile(I n, I ncol, const T* __restrict__ Q, long long ldq,
+                                                           const T* __restrict__ w, T* __restrict__ part, int nrb) {
+    __shared__ double lds8[4][CT];
+    const long long r0 = (long long)blockIdx.x * ROWS_PER_BLOCK;
+    const int c0 = blockIdx.y * CT;
+    double2 wv[RPT];
+    long long row[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        row[i] = r0 + 2LL * threadIdx.x + (long long)i * (2 * BLK);
+        if (row[i] + 1 < n) wv[i] = *reinterpret_cast<const double2*>(w + row[i]);
+        else { wv[i].x = (row[i] < n) ? w[row[i]] : 0.0; wv[i].y = 0.0; }
+    }
+    double acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        acc[c] = 0.0;
+        const int col = c0 + c;
+        if (col < ncol) {  // uniform
+            const T* q = Q + (long long)col * ldq;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                double2 qv;
+                if (row[i] + 1 < n) qv = (MODE & 2) ? *reinterpret_cast<const double2*>(q + row[i]) : ld_stream(q + row[i]);
+                else { qv.x = (row[i] < n) ? q[row[i]] : 0.0; qv.y = 0.0; }
+                acc[c] += qv.x * wv[i].x + qv.y * wv[i].y;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const double v = wave_sum(acc[c]);
+        if (lane == 0) lds8[wv_id][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < CT && c0 + (int)threadIdx.x < ncol)
+        part[(long long)(c0 + threadIdx.x) * nrb + blockIdx.x] =
+            (lds8[0][threadIdx.x] + lds8[1][threadIdx.x]) + (lds8[2][threadIdx.x] + lds8[3][threadIdx.x]);
+}
+
 __global__ __launch_bounds__(BLK) void cgs_dots_stage2(int nrb, const T* part, T* d_h) {
     __shared__ double lds[4];
     const T* p = part + (long long)blockIdx.x * nrb;
@@ -186,7 +232,7 @@ __global__ __launch_bounds__(BLK) void cgs_update_kernel(I n, I ncol, const T* _
             else { acc[i].x = (row[i] < n) ? w[row[i]] : 0.0; acc[i].y = 0.0; }
         } else { acc[i].x = 0.0; acc[i].y = 0.0; }
     }
-#pragma unroll 4
+#pragma unroll 4  // (8 columns in flight: 0.212 against 0.205 ms per CGS kernel -- slower)
     for (int jj = 0; jj < ncol; ++jj) {
         const int j = (MODE & 1) ? ncol - 1 - jj : jj;
         const double h = (j < 128) ? sh[j] : d_h[j];
@@ -762,8 +808,12 @@ void dfl_cgs_dots(I n, I ncol, const T* Q, int64_t ldq, const T* w, T* d_h, T* w
     if (ncol <= 0) return;
     int nrb = ceil_div(n, ROWS_PER_BLOCK);
     dim3 grid(nrb, ceil_div(ncol, CT));
+    // developer A/B, DFL_CGS_DOTS_TILE=1: all loads of a column tile before the reductions -- 0.2144-0.216 against 0.212-0.2138 ms:
+    // not faster (occupancy already hides the per-column barrier), so the per-column kernel stays
+    static const bool per_column = !(getenv("DFL_CGS_DOTS_TILE") && atoi(getenv("DFL_CGS_DOTS_TILE")) == 1);
     if (cgs_mode() & 2) cgs_dots_stage1<2><<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb);
-    else cgs_dots_stage1<0><<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb);
+    else if (per_column) cgs_dots_stage1<0><<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb);
+    else cgs_dots_stage1_tile<0><<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb);
     cgs_dots_stage2<<<ncol, BLK, 0, S(stream)>>>(nrb, work, d_h);
     DFL_LAUNCH_CHECK();
 }
