@@ -696,3 +696,61 @@ def test_pick_concurrent_stream_overlaps_the_library_stream(api):
     t_main = time.perf_counter() - t0
     assert t_side < 0.5 * t_main and t_main > 10e-3, (t_side, t_main)
     assert H.hipStreamDestroy(C.c_void_p(side)) == 0
+
+
+def test_interleaved_matvec_is_bitwise_the_reference_layout_matvec(api, oracle_lib):
+    """dfl_interleave4 + dfl_bcsr_spmv_x4 / DflMatrixFSMatVecX4Range (the matvec gathering x from x4[node][4] with one 16-byte
+    load per lane) against the reference-layout kernel: the same products in the same order, so y is BITWISE equal; row ranges;
+    MatrixMatVec takes the interleaved path by itself from 4096 nodes on and agrees with the oracle's matvec (1e-10).  The
+    single-precision-values matvec of PC_TWOLEVEL's opt-in mixed-precision mode agrees with the double one to 1e-6."""
+    m = kuhn_cube(17, jitter=0.2)                      # 5832 nodes: above the threshold of the automatic path
+    wg, dwg = synthetic_fields(m)
+    P = api.Problem(m, schedule=4)
+    L = api.lib()
+    try:
+        N = P.N
+        assert N >= 4096
+        wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
+        P.assemble_system(wg_d, dwg_d, None, want_J=True)
+        x = np.random.default_rng(3).normal(size=6 * N)
+        x_d, y_d, y2_d = api.DeviceArray.from_numpy(x), api.DeviceArray(6 * N), api.DeviceArray(6 * N)
+        x4_d = api.DeviceArray(4 * N)
+        L.dfl_interleave4.argtypes = [i32, i32, i32, vp, vp, vp]
+        L.dfl_bcsr_spmv_rows.argtypes = [i32, i32, vp, vp, vp, f64, vp, f64, vp, vp]
+        L.DflMatrixFSMatVecX4Range.argtypes = [C.POINTER(api.Matrix), vp, vp, i32, i32]
+        fs = C.cast(P.J.contents.data, C.POINTER(api.MatrixFS)).contents
+        spy = fs.spy1x1.contents
+        L.dfl_interleave4(0, N, N, x_d.ptr, x4_d.ptr, L.DflStream())
+        x4 = x4_d.numpy().reshape(N, 4)
+        assert np.array_equal(x4[:, :3], x[:3 * N].reshape(N, 3)) and np.array_equal(x4[:, 3], x[3 * N:4 * N])
+        L.dfl_bcsr_spmv_rows(N, N, spy.row_ptr, spy.col_ind, fs.block_val, 1.0, x_d.ptr, 0.0, y_d.ptr, L.DflStream())  # old gathers
+        L.DflMatrixFSMatVecX4Range(P.J, x4_d.ptr, y2_d.ptr, 0, N)
+        api.sync()
+        y_ref, y_x4 = y_d.numpy()[:4 * N], y2_d.numpy()[:4 * N]
+        assert np.array_equal(y_ref, y_x4)
+        y2_d.zero()
+        L.DflMatrixFSMatVecX4Range(P.J, x4_d.ptr, y2_d.ptr, 1000, 3000)       # a row range writes its rows only
+        api.sync()
+        yr = y2_d.numpy()
+        rows = np.zeros(N, bool); rows[1000:3000] = True
+        mask = np.concatenate([np.repeat(rows, 3), rows])
+        assert np.array_equal(yr[:4 * N][mask], y_ref[mask]) and not yr[:4 * N][~mask].any()
+        P.matvec(x_d, y2_d)                                                    # automatic path
+        api.sync()
+        assert np.array_equal(y2_d.numpy()[:4 * N], y_ref)
+        S = oracle_lib.System(m)
+        _, vals = S.assemble_system(wg, dwg, False, True)
+        yo = S.matvec(vals, x)
+        ok, e = close(y_ref, yo[:4 * N])
+        assert ok, e
+        # single-precision copy of the values
+        L.dfl_bcsr_values_to_f32.argtypes = [C.c_int64, vp, vp, vp]
+        L.dfl_bcsr_spmv_f32.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp]
+        valf = api.DeviceArray(spy.nnz * 16, np.float32)
+        L.dfl_bcsr_values_to_f32(spy.nnz * 16, fs.block_val, valf.ptr, L.DflStream())
+        y2_d.zero()
+        L.dfl_bcsr_spmv_f32(N, N, spy.row_ptr, spy.col_ind, valf.ptr, x_d.ptr, y2_d.ptr, L.DflStream())
+        api.sync()
+        assert np.abs(y2_d.numpy()[:4 * N] - y_ref).max() <= 1e-6 * np.abs(y_ref).max()
+    finally:
+        P.close()
