@@ -127,10 +127,10 @@ constexpr int ROWS_PER_BLOCK = BLK * RPT * 2;  // 2048 rows
 
 template <int MODE = 0>  // bit 1 = plain loads (developer A/B)
 __global__ __launch_bounds__(BLK) void cgs_dots_stage1(I n, I ncol, const T* __restrict__ Q, long long ldq,
-                                                      const T* __restrict__ w, T* __restrict__ part, int nrb) {
+                                                      const T* __restrict__ w, T* __restrict__ part, int nrb, int ct) {
     __shared__ double lds[4];
     const long long r0 = (long long)blockIdx.x * ROWS_PER_BLOCK;
-    const int c0 = blockIdx.y * CT;
+    const int c0 = blockIdx.y * ct;
     double2 wv[RPT];
     long long row[RPT];
 #pragma unroll
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(BLK) void cgs_dots_stage1(I n, I ncol, const T* __r
         if (row[i] + 1 < n) wv[i] = *reinterpret_cast<const double2*>(w + row[i]);
         else { wv[i].x = (row[i] < n) ? w[row[i]] : 0.0; wv[i].y = 0.0; }
     }
-    for (int c = 0; c < CT; ++c) {
+    for (int c = 0; c < ct; ++c) {
         const int col = c0 + c;
         if (col >= ncol) break;  // uniform
         const T* q = Q + (long long)col * ldq;
@@ -807,13 +807,19 @@ int64_t dfl_cgs_work_size(I n, I ncol) {
 void dfl_cgs_dots(I n, I ncol, const T* Q, int64_t ldq, const T* w, T* d_h, T* work, void* stream) {
     if (ncol <= 0) return;
     int nrb = ceil_div(n, ROWS_PER_BLOCK);
-    dim3 grid(nrb, ceil_div(ncol, CT));
+    // column tile of a workgroup: w is read once per (row block, tile), so with tiles of 8 a 41-column step re-read it six
+    // times (15 % of the kernel's bytes over a 40-iteration solve); tiles of 64 read it once while the grid still has
+    // thousands of row blocks.  Below 64k rows the grid would get too small: tiles of 8 there (DFL_CGS_TILE overrides).
+    static int tile_env = -1;
+    if (tile_env < 0) tile_env = getenv("DFL_CGS_TILE") ? atoi(getenv("DFL_CGS_TILE")) : 0;
+    const int ct = tile_env > 0 ? tile_env : CT;  // (measured: 0.2013-0.2017 ms per CGS kernel with 64, 0.2021-0.2026 with 8: the re-reads of w come out of the caches; not worth a change of the default)
+    dim3 grid(nrb, ceil_div(ncol, ct));
     // developer A/B, DFL_CGS_DOTS_TILE=1: all loads of a column tile before the reductions -- 0.2144-0.216 against 0.212-0.2138 ms:
     // not faster (occupancy already hides the per-column barrier), so the per-column kernel stays
     static const bool per_column = !(getenv("DFL_CGS_DOTS_TILE") && atoi(getenv("DFL_CGS_DOTS_TILE")) == 1);
-    if (cgs_mode() & 2) cgs_dots_stage1<2><<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb);
-    else if (per_column) cgs_dots_stage1<0><<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb);
-    else cgs_dots_stage1_tile<0><<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb);
+    if (cgs_mode() & 2) cgs_dots_stage1<2><<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb, ct);
+    else if (per_column) cgs_dots_stage1<0><<<grid, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb, ct);
+    else { dim3 grid8(nrb, ceil_div(ncol, CT)); cgs_dots_stage1_tile<0><<<grid8, BLK, 0, S(stream)>>>(n, ncol, Q, ldq, w, work, nrb); }
     cgs_dots_stage2<<<ncol, BLK, 0, S(stream)>>>(nrb, work, d_h);
     DFL_LAUNCH_CHECK();
 }
