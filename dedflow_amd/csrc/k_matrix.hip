@@ -425,7 +425,7 @@ __global__ __launch_bounds__(BLK) void pc_apply_kernel(I nrows, I N, const T* __
         if (MODE & 4) {
             __builtin_nontemporal_store(y0, y + 3 * i); __builtin_nontemporal_store(y1, y + 3 * i + 1);
             __builtin_nontemporal_store(y2, y + 3 * i + 2); __builtin_nontemporal_store(yp, y + 3LL * N + i);
-        } else {
+        } else if (y) {  // (y == NULL: the caller only wants the interleaved copy)
             y[3 * i + 0] = y0; y[3 * i + 1] = y1; y[3 * i + 2] = y2; y[3LL * N + i] = yp;
         }
         if (y4) {  // the interleaved copy the matvec gathers from (dfl_bcsr_spmv_x4): 32 B per node, written here for free
@@ -958,7 +958,7 @@ void dfl_pc_jacobi_apply_scaled_rows_x4(I nrows, I N, I n, const T* dinv33, cons
         if (d_nrm) pc_apply_kernel<true><<<g, BLK, 0, S(stream)>>>(nrows, N, dinv33, dinv1, w, d_nrm, q_out, y, y4);
         else pc_apply_kernel<false><<<g, BLK, 0, S(stream)>>>(nrows, N, dinv33, dinv1, w, nullptr, nullptr, y, y4);
     }
-    if (n > 4 * N)
+    if (n > 4 * N && y)
         tail_copy_kernel<<<ceil_div((long long)n - 4LL * N, BLK), BLK, 0, S(stream)>>>(4LL * N, n, w, d_nrm, q_out, y);
     DFL_LAUNCH_CHECK();
 }

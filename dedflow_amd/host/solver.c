@@ -361,6 +361,8 @@ b32 DflPcApplyFusedX4(PC* pc, index_type na, f64* w, const f64* d_nrm, f64* z, f
         const f64* d1 = (const f64*)((PCJacobi*)d->pc[1]->data)->diag;
         const index_type nrows = MatrixFSOwnedRows((Matrix*)pc->mat);
         if (z4) {
+            /* z == NULL (the caller reads nothing but the interleaved copy; vectors of 4N only): no reference-layout store */
+            ASSERT(z || na == 4 * N);
             dfl_pc_jacobi_apply_scaled_rows_x4(nrows, N, na, d33, d1, w, d_nrm, w, z, z4, DflStream());
             return TRUE;
         }
@@ -713,6 +715,9 @@ static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe) {
     }
     const index_type x4_N = MatrixFSBlockValues(A) ? ((MatrixFS*)A->data)->spy1x1->num_row : 0;
     const b32 x4_path = x4_env && !dist && !fuse_pc && x4_N >= x4_min && MatrixFSOwnedRows(A) == x4_N && na >= 4 * x4_N;
+    index_type jt_N = 0, jt_rows = 0;
+    const f64 *jt_a = NULL, *jt_b = NULL;
+    const b32 x4_skip_z = x4_path && jacobi_tree_data(pc, &jt_a, &jt_b, &jt_N, &jt_rows) && na == 4 * jt_N && jt_N == x4_N;
     /* partitioned, split rows: the same gathers; owned part of the copy from the producer, ghost part behind the unpack */
     const index_type x4_owned = dist ? MatrixFSOwnedRows(A) : x4_N;
     const b32 x4_dist = x4_env && dist && split_rows && x4_N >= x4_min && na >= 4 * x4_N;
@@ -770,7 +775,10 @@ static b32 gmres_run(Matrix* A, f64* x, f64* b, Krylov* ksp, b32 force_probe) {
                    preconditioner is followed by one interleave pass */
                 f64* const z4 = Q + (size_t)na * (size_t)(m + 1); /* the spare column of the basis block */
                 b32 wrote = FALSE;
-                DFL_TIMED(DFL_TAG_PC, wrote = DflPcApplyFusedX4(pc, na, QCOL(iter), ex->nrm + iter, zk, z4));
+                /* with the Jacobi tree on 4N-vectors nothing reads z in the reference layout (tmp is rewritten before its next
+                   use): the kernel then stores the interleaved copy only -- 32 B per node and iteration less to write */
+                f64* const zref = (x4_skip_z && !Zb) ? NULL : zk;
+                DFL_TIMED(DFL_TAG_PC, wrote = DflPcApplyFusedX4(pc, na, QCOL(iter), ex->nrm + iter, zref, z4));
                 if (!wrote) dfl_interleave4(0, x4_N, x4_N, zk, z4, s);
                 DFL_TIMED(DFL_TAG_SPMV, DflMatrixFSMatVecX4Range(A, z4, QCOL(iter + 1), 0, x4_N));
                 goto matvec_done;

@@ -420,7 +420,8 @@ void dfl_amg_restrict(dfl_index Nc, const dfl_index* aoff, const dfl_index* anod
  * one gather instruction and about one L2 request less per nodal nonzero: 0.50 against 0.57 ms at 10M tets (6.95 TB/s),
  * bitwise the same y.  dfl_interleave4 writes the copy for nodes [node0, node1); y rows [row0, row1) = alpha * A x. */
 /* the fused Jacobi-tree application (dfl_pc_jacobi_apply[_scaled]_rows; d_nrm == NULL: unscaled, q_out unused) that ALSO
- * writes y interleaved into y4[node][4] for the owned rows -- the matvec that follows needs no interleave pass */
+ * writes y interleaved into y4[node][4] for the owned rows -- the matvec that follows needs no interleave pass; y == NULL:
+ * only the interleaved copy (n == 4N then: the phi / T tail has nowhere to go) */
 void dfl_pc_jacobi_apply_scaled_rows_x4(dfl_index nrows, dfl_index N, dfl_index n, const dfl_value* dinv33, const dfl_value* dinv1,
                                         const dfl_value* w, const dfl_value* d_nrm, dfl_value* q_out, dfl_value* y, dfl_value* y4,
                                         void* stream);
