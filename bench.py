@@ -47,7 +47,7 @@ def algorithmic_bytes(N, T, nnz1, its):
         "asm_lhs": 128.0 * nnz1 + 16.0 * T + 120.0 * N,
         "asm_lhs_colored": T * (16.0 + 4.0 + 4096.0) + 120.0 * N,
         "asm_rhs": T * (20.0 + 384.0) + 120.0 * N,                           # per F assembly
-        "pc_apply": (9 + 1) * 8.0 * N + 3 * 8.0 * n4,                        # per apply (z written twice: reference layout + interleaved)
+        "pc_apply": (9 + 1) * 8.0 * N + 2 * 8.0 * n4,                        # per apply (w read, z written -- interleaved, for the matvec)
         "cgs": [2 * 8.0 * n4 * (k + 1) + 24.0 * n4 for k in range(its)],     # dots+update of step k
     }
 
@@ -293,7 +293,7 @@ def main():
     if "asm_lhs" in kernels:  # what the reference-shaped colored scatter would move, for orientation only
         kernels["asm_lhs"]["colored_scatter_bytes_per_assembly"] = ab["asm_lhs_colored"]
     c, t, _ = prof["asm_rhs"]; entry("asm_rhs", ab["asm_rhs"] * K, c, t, "404*T+120N per F assembly = the colored-scatter byte model (lane-per-tet persistent wave kernel + ordered node sum: 2 launches; PMC traffic: roofline.traffic / profiles/pmc_traffic_M119.json)")
-    c, t, _ = prof["pc_apply"]; entry("pc_apply", ab["pc_apply"] * c, c, t, "80N+96N per apply (z also written interleaved, 32N, for the matvec that gathers from it)")
+    c, t, _ = prof["pc_apply"]; entry("pc_apply", ab["pc_apply"] * c, c, t, "80N+64N per apply (z is written interleaved for the matvec that gathers from it)")
     cd, td, _ = prof["cgs_dots"]; cu, tu, _ = prof["cgs_update"]
     entry("cgs", sum(ab["cgs"]) * K, cd + cu, td + tu, "2*8*4N*(k+1)+24*4N per Arnoldi step k")
     dominant = max(kernels, key=lambda k: kernels[k]["total_ms_per_step"])
