@@ -221,7 +221,12 @@ __global__ __launch_bounds__(BLK) void cgs_update_kernel(I n, I ncol, const T* _
     __shared__ double sh[128];
     for (int j = threadIdx.x; j < ncol && j < 128; j += BLK) sh[j] = d_h[j];
     __syncthreads();
-    const long long r0 = (long long)blockIdx.x * UROWS;
+    long long blk = blockIdx.x;
+    if (MODE & 4) {  // developer A/B: one contiguous slab of row chunks per XCD (workgroup b runs on XCD b % 8), as the SpMV
+        const long long per = (gridDim.x + 7) >> 3;
+        blk = (blk & 7) * per + (blk >> 3);
+    }
+    const long long r0 = blk * UROWS;
     long long row[UPT];
     double2 acc[UPT];
 #pragma unroll
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(BLK) void cgs_update_kernel(I n, I ncol, const T* _
     }
     if (part) {
         double r = block_sum_256(ss, lds);
-        if (threadIdx.x == 0) part[blockIdx.x] = r;
+        if (threadIdx.x == 0 && blk < gridDim.x) part[blk] = r;  // (slab order: the partial of row chunk blk, as without the remap)
     }
 }
 
@@ -786,7 +791,7 @@ void dfl_dscal_inv_dev(I n, const T* d_scale, T* x, void* stream) {
 
 static int cgs_mode() {
     static int m = -1;
-    if (m < 0) m = getenv("DFL_CGS_MODE") ? atoi(getenv("DFL_CGS_MODE")) & 3 : 0;
+    if (m < 0) m = getenv("DFL_CGS_MODE") ? atoi(getenv("DFL_CGS_MODE")) & 7 : 0;
     return m;
 }
 #define CGS_UPDATE_LAUNCH(...)                                                                     \
@@ -795,6 +800,7 @@ static int cgs_mode() {
             case 1: cgs_update_kernel<true, 1><<<g, BLK, 0, S(stream)>>>(__VA_ARGS__); break;      \
             case 2: cgs_update_kernel<true, 2><<<g, BLK, 0, S(stream)>>>(__VA_ARGS__); break;      \
             case 3: cgs_update_kernel<true, 3><<<g, BLK, 0, S(stream)>>>(__VA_ARGS__); break;      \
+            case 4: cgs_update_kernel<true, 4><<<(g + 7) / 8 * 8, BLK, 0, S(stream)>>>(__VA_ARGS__); break; \
             default: cgs_update_kernel<true, 0><<<g, BLK, 0, S(stream)>>>(__VA_ARGS__); break;     \
         }                                                                                          \
     } while (0)
