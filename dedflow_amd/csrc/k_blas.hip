@@ -212,7 +212,7 @@ __global__ __launch_bounds__(BLK) void cgs_dots_stage2(int nrb, const T* part, T
 }
 
 // w -= Q h (SUB) or y = Q c (!SUB); optional partial ||w||^2 per block
-constexpr int UPT = 2;  // double2 slots per thread
+constexpr int UPT = 2;  // double2 slots per thread (1 and 4 measured: 0.2093 against 0.2028 ms per CGS kernel)
 constexpr int UROWS = BLK * UPT * 2;
 template <bool SUB, int MODE = 0>  // MODE (developer A/B, DFL_CGS_MODE): bit 0 = columns walked last to first, bit 1 = plain loads
 __global__ __launch_bounds__(BLK) void cgs_update_kernel(I n, I ncol, const T* __restrict__ Q, long long ldq,
