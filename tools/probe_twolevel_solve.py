@@ -15,6 +15,8 @@ wg_d, dwg_d = api.DeviceArray.from_numpy(wg), api.DeviceArray.from_numpy(dwg)
 F_d, x_d = api.DeviceArray(6 * N), api.DeviceArray(6 * N)
 P.assemble_system(wg_d, dwg_d, F_d, want_J=False)
 P.assemble_system(wg_d, dwg_d, None, want_J=True)
+if os.environ.get("DFL_AGG"):
+    L.KrylovSetAggregateSize(P.ksp, int(os.environ["DFL_AGG"]))
 L.KrylovSetPCType(P.ksp, api.PC_TWOLEVEL)
 for rep in range(3):
     x_d.zero()
