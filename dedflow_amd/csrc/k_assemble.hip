@@ -321,7 +321,24 @@ __global__ __launch_bounds__(256) void rhs_node_sum_kernel(I N, const I* __restr
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     double f[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (I q = goff[i]; q < goff[i + 1]; ++q) {
+    const I q1 = goff[i + 1];
+    I q = goff[i];
+    // four records in flight (indices first, then the 12 loads): a node has 2-8 partial records and the one-at-a-time walk was a
+    // chain of dependent loads per record; the additions stay in record order
+    for (; q + 4 <= q1; q += 4) {
+        const I g0 = gidx[q], g1 = gidx[q + 1], g2 = gidx[q + 2], g3 = gidx[q + 3];
+        const double2* s0 = reinterpret_cast<const double2*>(partial + (long long)g0 * 6);
+        const double2* s1 = reinterpret_cast<const double2*>(partial + (long long)g1 * 6);
+        const double2* s2 = reinterpret_cast<const double2*>(partial + (long long)g2 * 6);
+        const double2* s3 = reinterpret_cast<const double2*>(partial + (long long)g3 * 6);
+        const double2 a0 = s0[0], a1 = s0[1], a2 = s0[2], b0 = s1[0], b1 = s1[1], b2 = s1[2];
+        const double2 c0 = s2[0], c1 = s2[1], c2 = s2[2], d0 = s3[0], d1 = s3[1], d2 = s3[2];
+        f[0] += a0.x; f[1] += a0.y; f[2] += a1.x; f[3] += a1.y; f[4] += a2.x; f[5] += a2.y;
+        f[0] += b0.x; f[1] += b0.y; f[2] += b1.x; f[3] += b1.y; f[4] += b2.x; f[5] += b2.y;
+        f[0] += c0.x; f[1] += c0.y; f[2] += c1.x; f[3] += c1.y; f[4] += c2.x; f[5] += c2.y;
+        f[0] += d0.x; f[1] += d0.y; f[2] += d1.x; f[3] += d1.y; f[4] += d2.x; f[5] += d2.y;
+    }
+    for (; q < q1; ++q) {
         const double2* src = reinterpret_cast<const double2*>(partial + (long long)gidx[q] * 6);
         const double2 a0 = src[0], a1 = src[1], a2 = src[2];
         f[0] += a0.x; f[1] += a0.y; f[2] += a1.x; f[3] += a1.y; f[4] += a2.x; f[5] += a2.y;
